@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X hot path.
+
+Metric (BASELINE.json): complex IQ MS/s end-to-end, device-resident int16 capture ->
+48 kHz PCM16 audio on the host, for BASELINE config 2: synthetic 60 s @ 10 MS/s, one NFM
+channel (+25 kHz offset, bw 12.5 kHz, de-emphasis 300 us, requested chunk 1 048 576 ->
+effective 4 194 304, D = 104, 6401 taps).
+
+One *step* = one pass of the whole hot path over the capture:
+  mixer-sign probe -> fused ingest+mix+FIR+decimate -> discriminator -> de-emphasis scan ->
+  peak/clip -> 48 kHz polyphase resample -> PCM16 -> D2H of the audio [-> RCCL gather at N>1].
+The capture is resident in HBM before the timed region (the first 5 s are the reference's
+seed-42 generator, tiled to 60 s in HBM -- SURVEY.md section 8(d)).
+
+N > 1 (launched by torch.distributed.run): every rank processes its own independent capture
+(BASELINE config 4 pattern, seeds 42+rank), no data-path collective, only the finished 48 kHz
+audio is gathered to rank 0 over RCCL.  scaling = "weak".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=60.0, help="capture length (config 2: 60 s)")
+    ap.add_argument("--sample-rate", type=float, default=10e6)
+    ap.add_argument("--unique-seconds", type=float, default=5.0, help="seed-42 prefix generated on the host, then tiled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chunks", type=int, default=5, help="reference chunks timed for the CPU baseline")
+    return ap.parse_args()
+
+
+def main() -> None:
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import iq_to_audio_amd as A
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.benchmark import synthetic_iq_s16
+    from iq_to_audio_amd.processing import ChannelDemod, Resampler48k
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    A.native.lib()
+    A.native.require_gpu()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    fs, f_off, bw = float(args.sample_rate), 25e3, 12_500.0
+    n_total = int(round(fs * args.seconds))
+    n_unique = min(n_total, int(round(fs * args.unique_seconds)))
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    chunk = P.tune_chunk_size(fs, 1_048_576)
+    taps = A.design_channel_filter(fs, bw, d)
+
+    # ---- synthetic capture, resident in HBM ---------------------------------------------------
+    host = synthetic_iq_s16(fs, n_unique / fs, f_off, seed=42 + rank).reshape(-1)
+    tile = torch.from_numpy(host).to(D.device())
+    reps = -(-n_total // n_unique)
+    raw = tile.repeat(reps)[: 2 * n_total].contiguous()
+    del tile
+    torch.cuda.synchronize()
+
+    n_dec = -(-n_total // d)
+    starts = P.chunk_output_starts(chunk, d, 0, n_total)
+    rs = Resampler48k(fs_ch)
+    n48 = rs.plan.n_out(n_dec)
+    pcm_host = torch.empty(n48, dtype=torch.int16).pin_memory()
+    gathered = [torch.empty(n48, dtype=torch.float32, device=D.device()) for _ in range(world)] if (world > 1 and rank == 0) else None
+    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
+    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
+    z = D.empty(n_dec, "complex64")
+    audio = D.empty(n_dec, "float32")
+
+    def step(i: int):
+        sign = A.choose_mix_sign(raw[: 2 * min(chunk, n_total)], fs, f_off, taps, d, fmt="s16")
+        chan = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=sign, decimation=d, fmt="s16")
+        ev_k0[i].record()
+        chan.process(raw, out_dev=z)
+        ev_k1[i].record()
+        dem = ChannelDemod("nfm", fs_ch, deemph_us=300.0, agc_enabled=True)
+        dem.process(z, starts, audio)
+        y48 = rs.process(audio)
+        pcm = rs.to_pcm16(y48)
+        pcm_host.copy_(pcm, non_blocking=True)
+        if world > 1:
+            dist.gather(y48, gathered, dst=0)
+        return sign, dem, y48
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sign, dem, y48 = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=D.device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = [ev_k0[args.warmup + i].elapsed_time(ev_k1[args.warmup + i]) for i in range(args.steps)]
+    kern_avg_ms = float(np.mean(kern_ms))
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_total / (elapsed / args.steps) / 1e6  # MS/s, whole job
+
+    # algorithmic bytes per complex input sample: int16 I+Q read once + 48 kHz f32 out
+    bytes_per_sample = 4.0 + 1 * 4.0 * 48_000.0 / fs
+    algo_bytes = bytes_per_sample * n_total
+    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_summary.json"
+    if pmc.exists():
+        with pmc.open() as fh:
+            rec = json.load(fh)
+        if rec.get("workload_frames") == n_total and rec.get("kernel", "").startswith("k_channelize"):
+            traffic = rec.get("hbm_bytes_per_launch")
+
+    out = {
+        "metric": "complex IQ MS/s end-to-end (ingest->48 kHz audio)",
+        "value": round(value, 1),
+        "unit": "MS/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE config 2: synthetic {args.seconds:g} s @ {fs/1e6:g} MS/s int16 I/Q, 1 NFM channel, "
+                        f"+25 kHz, bw 12.5 kHz, D={d}, {len(taps)} taps, chunk {chunk}",
+            "frames_per_gpu": n_total,
+            "parallelism": f"{world} independent capture(s), one per GPU; RCCL gather of 48 kHz audio only",
+            "audio_samples_48k": int(n48),
+            "mix_sign": int(sign),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_channelize_v1<s16>",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5),
+            "traffic": traffic,
+            "kernel_ms": round(kern_avg_ms, 4),
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "kernel_gsps": round(n_total / (kern_avg_ms * 1e-3) / 1e9, 2),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_ref as O
+
+        n_cpu = min(n_unique, args.cpu_chunks * chunk)
+        t1 = time.perf_counter()
+        ref = O.run_chain(host[: 2 * n_cpu], sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+        cpu_s = time.perf_counter() - t1
+        # parity of the benchmarked GPU output against the oracle on the same prefix
+        got = audio[: ref.audio.size].cpu().numpy()
+        err = float(np.sqrt(np.mean((got.astype(np.float64) - ref.audio) ** 2)))
+        out["cpu_baseline"] = {
+            "value": round(n_cpu / cpu_s / 1e6, 2),
+            "unit": "MS/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"first {n_cpu} frames ({n_cpu / fs:.2f} s of signal) of the same capture, oracle/cpu_ref.run_chain "
+                      f"(fp64 NCO + complex128 131072-pt scipy.fft overlap-save + slice decimate + NFM), "
+                      f"{cpu_s:.1f} s on {os.cpu_count()} host cpus (1-D FFTs are single-threaded)",
+        }
+        out["parity"] = {"rms_err_vs_oracle_fs_channel": err, "samples_compared": int(ref.audio.size), "bar": 1e-4}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

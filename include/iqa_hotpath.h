@@ -1,0 +1,188 @@
+/*
+ * iqa_hotpath.h -- C ABI of the MI355X-native channelize -> demodulate hot path.
+ *
+ * This is the drop-in boundary for the DSP stages of rknightion/iq-to-audio
+ * (src/iq_to_audio/processing.py and src/iq_to_audio/decoders/).  Every entry
+ * point names the reference interface it replaces ("ref:" lines, paths relative to
+ * the reference's src/iq_to_audio/).  The reference is pure Python, so its "FFI" is
+ * a ctypes binding; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - All `*_dev` pointers are DEVICE (HBM) pointers on the current HIP device;
+ *     `stream` is a hipStream_t passed as void* (0 = default stream).  Calls only
+ *     enqueue work: they never synchronise, allocate or free, so they can be
+ *     captured into a hipGraph.
+ *   - Complex samples are interleaved float pairs (re, im) == numpy complex64.
+ *   - Raw capture frames are interleaved pairs in the capture's own sample format
+ *     (iqa_fmt); one frame = one complex sample.
+ *   - Return value: IQA_OK or an iqa_status error; iqa_last_error() gives the text
+ *     (thread-local).  The Python shim maps IQA_EINVAL -> ValueError, everything
+ *     else -> RuntimeError, as the reference raises them.
+ *   - Streaming state (FIR history, discriminator previous sample, IIR states, peak)
+ *     lives in small caller-owned device buffers whose layouts are given below, so
+ *     the library has no globals and is re-entrant per stream.
+ */
+#ifndef IQA_HOTPATH_H
+#define IQA_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IQA_ABI_VERSION 1
+
+typedef enum {
+    IQA_OK = 0,
+    IQA_EINVAL = 1, /* bad argument (ValueError in the reference) */
+    IQA_EHIP = 2,   /* HIP runtime / launch failure (RuntimeError) */
+    IQA_ESTATE = 3  /* call sequence error, e.g. process before setup (RuntimeError) */
+} iqa_status;
+
+/* Sample format of a raw capture frame.  ref: input_formats.py:45-94 (_FORMAT_MAP)
+ * and the ffmpeg conversion the reference relies on (processing.py:113-158):
+ *   S16: x/32768   U8: (x-128)/128   F32: unchanged (also = complex64 stage data). */
+typedef enum { IQA_FMT_S16 = 0, IQA_FMT_U8 = 1, IQA_FMT_F32 = 2 } iqa_fmt;
+
+/* ref: IQReader._extract_iq, processing.py:268-279 */
+typedef enum { IQA_ORDER_IQ = 0, IQA_ORDER_QI = 1, IQA_ORDER_IQ_INV = 2, IQA_ORDER_QI_INV = 3 } iqa_iq_order;
+
+/* ref: create_decoder, decoders/__init__.py:9-24 */
+typedef enum { IQA_DEMOD_NFM = 0, IQA_DEMOD_AM = 1, IQA_DEMOD_USB = 2, IQA_DEMOD_LSB = 3 } iqa_demod;
+
+int iqa_abi_version(void);
+const char *iqa_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Channelizer: ingest + NCO mix + channel FIR + decimate in ONE kernel.      *
+ *                                                                            *
+ * ref: the first half of the per-chunk body of ProcessingPipeline.run,       *
+ *      processing.py:1088-1096, i.e.                                         *
+ *        IQReader._extract_iq        processing.py:268-279                   *
+ *        ComplexOscillator.mix       processing.py:289-297                   *
+ *        OverlapSaveFIR.process      processing.py:325-346                   *
+ *        Decimator.process           processing.py:354-360                   *
+ *                                                                            *
+ * Math: z[m] = e^{j*2pi*rot(m)} * sum_k g[k] * x[m*D - k],  m = m_first..    *
+ * where g[k] = h[k]*e^{+j*s*w*k} are the channel taps pre-rotated on the     *
+ * host (so no per-input-sample trig is needed), and rot() is a 64-bit        *
+ * fixed-point phase in turns.  Equal to mix -> filter -> keep every D-th     *
+ * sample of the reference, with zero initial state (causal convolution, group *
+ * delay not compensated).                                                     *
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t fmt;          /* iqa_fmt of raw frames */
+    int32_t ntaps;        /* L */
+    int32_t decimation;   /* D >= 1 */
+    int32_t conj_sum;     /* 1: conjugate the tap sum before rotation (host folds iq_order into taps + this flag:
+                           *    x = c*conj(r)  =>  sum g*x = c*conj(sum conj(g)*r)) */
+    int32_t rotate;       /* 0: no output rotation (plain FIR stage), 1: apply rot(m) */
+    int32_t reserved;
+    uint64_t rot_step;    /* phase advance per OUTPUT sample, turns * 2^64 (wraps) */
+    uint64_t rot_base;    /* phase of output m = 0 (global), turns * 2^64 */
+    float out_scale_re;   /* constant complex factor applied last (1, j, -j for iq_order) */
+    float out_scale_im;
+} iqa_chan_params;
+
+/*
+ * taps_dev    : float2[ntaps_padded] complex taps in WINDOW order (taps_dev[i] multiplies
+ *               x[n0-(L-1)+i]), zero padded to iqa_taps_padded_len(L); already scaled by the
+ *               ingest scale (1/32768 for S16, 1/128 for U8).
+ * raw_dev     : frames [0, n_frames) of this block; frame 0 has GLOBAL index `consumed`.
+ * hist_dev    : the L-1 frames preceding raw_dev (same fmt), or NULL for "all zeros"
+ *               (start of capture).  ref: OverlapSaveFIR.state, processing.py:323,341-345.
+ * m_first     : global index of the first output to produce; outputs m_first..m_first+n_out-1
+ *               need frames up to (m_first+n_out-1)*D, all of which must be < consumed+n_frames.
+ * z_out_dev   : float2[n_out].
+ */
+int64_t iqa_taps_padded_len(int32_t ntaps);
+int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *raw_dev, int64_t n_frames,
+                   int64_t consumed, const void *hist_dev, int64_t m_first, int64_t n_out, void *z_out_dev,
+                   void *stream);
+
+/* Copy the last L-1 frames of (hist | raw) into hist (handles n_frames < L-1 by shifting).
+ * ref: OverlapSaveFIR.process state update, processing.py:341-345.
+ * hist_next_dev must not alias hist_dev. */
+int iqa_history_update(int32_t fmt, int32_t ntaps, const void *hist_dev, const void *raw_dev, int64_t n_frames,
+                       void *hist_next_dev, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Stand-alone stages of the pluggable stage API                              *
+ * ------------------------------------------------------------------------- */
+
+/* ref: ComplexOscillator.mix, processing.py:289-297 (+ ingest conversion when fmt != F32).
+ * out[i] = cvt(in[i]) * exp(j*(phase0 + step*i)), phase ramp evaluated in float64 exactly as
+ * the reference does; the caller carries phase0 = (phase0 + step*n) mod 2pi on the host. */
+int iqa_oscillator_mix(int32_t fmt, int32_t iq_order, const void *in_dev, int64_t n, double phase0, double step,
+                       void *out_dev, void *stream);
+
+/* ref: Decimator.process, processing.py:354-360.  out[i] = in[first + i*D]. */
+int iqa_decimate(const void *in_dev, int64_t n, int64_t first, int32_t D, void *out_dev, int64_t n_out,
+                 void *stream);
+
+/* mean(|z|^2) over z[skip:n] accumulated in float64 into *power_dev (double[1], overwritten).
+ * ref: choose_mix_sign, processing.py:650-658; baseband_power, processing.py:1105. */
+int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *power_dev, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Demodulators (channel rate)                                                 *
+ * ------------------------------------------------------------------------- */
+
+/* ref: QuadratureDemod.process, decoders/nfm.py:17-24.
+ * out[i] = atan2 of z[i]*conj(z[i-1]); prev_dev = float2[1] state (init 1+0j), updated. */
+int iqa_quadrature(const void *z_dev, int64_t n, void *prev_dev, void *out_dev, void *stream);
+
+/* ref: AMDecoder.process envelope, decoders/am.py:28.  out[i] = |z[i]| (float32). */
+int iqa_envelope(const void *z_dev, int64_t n, void *out_dev, void *stream);
+
+/* ref: SSBDecoder.process, decoders/ssb.py:42-43.  out[i] = real(z[i]) for usb AND lsb. */
+int iqa_real_part(const void *z_dev, int64_t n, void *out_dev, void *stream);
+
+/*
+ * First-order recurrences as parallel affine scans (float64 scan arithmetic).
+ *
+ * iqa_deemphasis : y[n] = (1-a)*x[n] + a*y[n-1]        ref: DeemphasisFilter.process, decoders/nfm.py:48-62
+ *                  state_dev = double[1] holding y[last] (reference keeps a*y[last]); init 0.
+ * iqa_dc_block   : y[n] = x[n] - x[n-1] + r*y[n-1]     ref: DCBlocker.process, decoders/common.py:16-30
+ *                  state_dev = double[2] {x[last], y[last]}; init 0,0.
+ * iqa_agc        : g[n] = g[n-1] + decay*(target/|x[n]| - g[n-1]) if |x[n]| > 1e-6 else g[n-1];
+ *                  out[n] = x[n]*g[n]; g restarts at 1.0 at every multiple of `reset_period`
+ *                  counted from element index `reset_phase` (the reference restarts it on every
+ *                  process() call, i.e. at every chunk boundary).  ref: SSBDecoder._apply_agc,
+ *                  decoders/ssb.py:65-80.  reset_starts_dev: optional sorted int64[n_resets] of
+ *                  element indices where the gain restarts (index 0 always restarts).
+ * work_dev: scratch, at least iqa_scan_workspace_bytes(n) bytes.
+ */
+int64_t iqa_scan_workspace_bytes(int64_t n);
+int iqa_deemphasis(const void *x_dev, int64_t n, double alpha, void *state_dev, void *y_dev, void *work_dev,
+                   void *stream);
+int iqa_dc_block(const void *x_dev, int64_t n, double radius, void *state_dev, void *y_dev, void *work_dev,
+                 void *stream);
+int iqa_agc(const void *x_dev, int64_t n, double target, double decay, const void *reset_starts_dev,
+            int64_t n_resets, void *y_dev, void *work_dev, void *stream);
+
+/* ref: AudioWriter.write, processing.py:440-456: peak = max(peak, max|a|) BEFORE the clip, then
+ * clip to +-0.99.  peak_dev = float[1] (running, init 0).  In-place allowed (out_dev == a_dev).
+ * Also accumulates sum(a^2) (pre-clip, float64) into sumsq_dev[seg] for the rms_dbfs statistic
+ * (ref: decoders/nfm.py:88-89), where seg = index into seg_starts_dev (sorted int64[n_segs],
+ * seg_starts[0] == 0); pass NULL/0 to skip.  peak_dev and out_dev may each be NULL (statistics only). */
+int iqa_writer_clip(const void *a_dev, int64_t n, void *peak_dev, const void *seg_starts_dev, int64_t n_segs,
+                    void *sumsq_dev, void *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * 48 kHz resampler (replaces the `ffmpeg -ar 48000` leg, processing.py:399-418) *
+ * BUILD-DEFINED SPEC (the reference's is libswresample: parity unpinned).      *
+ *   y[j] = sum_t table[p][t] * x[q - (t - T)],  c = (j0+j)*down, q = c / up, p = c % up          *
+ * table_dev: double[up][2T+1] polyphase rows; x zero outside [0, n_in).       *
+ * ------------------------------------------------------------------------- */
+int iqa_resample(const void *x_dev, int64_t n_in, const void *table_dev, int32_t up, int32_t down, int32_t T,
+                 int64_t j0, int64_t n_out, void *y_dev, void *stream);
+
+/* float32 -> PCM16 (round-half-even of y*32768, saturated).  Build-defined, see above. */
+int iqa_float_to_pcm16(const void *y_dev, int64_t n, void *pcm_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQA_HOTPATH_H */

@@ -1,0 +1,28 @@
+"""iq-to-audio hot path, MI355X-native.
+
+Drop-in for the DSP surface of the reference's ``iq_to_audio.processing`` and
+``iq_to_audio.decoders`` modules; all arithmetic runs in hand-written gfx950 HIP kernels
+behind the C ABI in ``include/iqa_hotpath.h``.  Importing the package does not touch the GPU
+or the native library; the first stage call does (and raises if either is missing).
+
+The directory is named ``iq-to-audio_amd``; import it as ``iq_to_audio_amd``.
+"""
+from __future__ import annotations
+
+__version__ = "0.1.0"
+
+from . import _native as native  # noqa: F401
+from .decoders import Decoder, DecoderStats, create_decoder  # noqa: F401
+from .processing import (  # noqa: F401
+    Channelizer,
+    ComplexOscillator,
+    Decimator,
+    OverlapSaveFIR,
+    ProcessingCancelled,
+    ProcessingConfig,
+    ProcessingPipeline,
+    ProcessingResult,
+    choose_mix_sign,
+    design_channel_filter,
+    tune_chunk_size,
+)

@@ -1,0 +1,66 @@
+"""Small device-memory helpers.  PyTorch is used for allocation, streams and copies only;
+all arithmetic happens in the HIP library behind ``_native``."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as N
+
+
+def torch_mod():
+    return N.require_gpu()
+
+
+def device(index: int | None = None):
+    torch = torch_mod()
+    return torch.device("cuda", torch.cuda.current_device() if index is None else index)
+
+
+def is_tensor(x) -> bool:
+    try:
+        import torch
+
+        return isinstance(x, torch.Tensor)
+    except Exception:
+        return False
+
+
+def to_device(x, dtype: str):
+    """numpy array / host tensor / device tensor -> contiguous device tensor of ``dtype``
+    ('complex64', 'float32', 'int16', 'uint8', 'int64', 'float64')."""
+    torch = torch_mod()
+    td = getattr(torch, dtype)
+    if is_tensor(x):
+        t = x
+        if t.dtype != td:
+            t = t.to(td)
+        if not t.is_cuda:
+            t = t.to(device(), non_blocking=False)
+        return t.contiguous()
+    arr = np.ascontiguousarray(np.asarray(x), dtype=np.dtype(dtype))
+    if arr.size == 0:
+        return torch.empty(0, dtype=td, device=device())
+    return torch.from_numpy(arr).to(device())
+
+
+def like_input(result, template):
+    """Return ``result`` (device tensor) in the container type of ``template``:
+    numpy in -> numpy out (as the reference's stages do), tensor in -> device tensor out."""
+    if is_tensor(template):
+        return result
+    return result.cpu().numpy()
+
+
+def empty(n: int, dtype: str):
+    torch = torch_mod()
+    return torch.empty(int(n), dtype=getattr(torch, dtype), device=device())
+
+
+def zeros(n: int, dtype: str):
+    torch = torch_mod()
+    return torch.zeros(int(n), dtype=getattr(torch, dtype), device=device())
+
+
+def from_numpy(arr: np.ndarray):
+    torch = torch_mod()
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(device())

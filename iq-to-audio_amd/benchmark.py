@@ -1,0 +1,69 @@
+"""Synthetic benchmark harness (reference ``benchmark.py``): generate the tone+AWGN capture,
+run the pipeline on it, report "x realtime"."""
+from __future__ import annotations
+
+import logging
+import math
+import tempfile
+import time
+from collections.abc import Mapping
+from pathlib import Path
+
+import numpy as np
+
+from . import iqio
+from .processing import ProcessingConfig, ProcessingPipeline
+
+LOG = logging.getLogger(__name__)
+
+
+def synthetic_iq_s16(sample_rate: float, seconds: float, freq_offset: float, *, amplitude: float = 0.7,
+                     noise_std: float = 0.02, seed: int = 42) -> np.ndarray:
+    """int16 (N, 2) I/Q of the reference's synthetic capture (benchmark.py:19-38): complex tone at
+    ``freq_offset`` (amplitude 0.7) + AWGN (sigma 0.02 per rail, ``default_rng(42).normal(size=(N,2))``),
+    float32, clipped to +-0.999, PCM16 = rint(x*32767) (libsndfile's float->PCM_16 rule)."""
+    total = int(round(sample_rate * seconds))
+    if total <= 0:
+        raise ValueError("Benchmark duration is too short to generate samples.")
+    t = np.arange(total, dtype=np.float64) / sample_rate
+    tone = np.exp(1j * 2.0 * math.pi * freq_offset * t)
+    noise = np.random.default_rng(seed).normal(scale=noise_std, size=(total, 2))
+    iq = np.column_stack((amplitude * tone.real + noise[:, 0], amplitude * tone.imag + noise[:, 1]))
+    iq = np.clip(iq.astype(np.float32), -0.999, 0.999)
+    return np.rint(iq.astype(np.float64) * 32767.0).astype(np.int16)
+
+
+def _generate_synthetic_iq(path: Path, sample_rate: float, seconds: float, freq_offset: float, **kw) -> None:
+    iqio.write_wav_iq(path, synthetic_iq_s16(sample_rate, seconds, freq_offset, **kw), int(sample_rate), "s16")
+
+
+def run_benchmark(*, seconds: float, sample_rate: float, freq_offset: float, center_freq: float | None,
+                  target_freq: float | None, base_kwargs: Mapping[str, object] | None) -> int:
+    """Same contract as the reference's ``run_benchmark`` (benchmark.py:41-127): returns 0 on success
+    and logs "Benchmark processed N IQ samples in T s (Rx realtime)"."""
+    if seconds <= 0:
+        raise ValueError("Benchmark duration must be positive.")
+    if sample_rate <= 0:
+        raise ValueError("Benchmark sample rate must be positive.")
+    if abs(freq_offset) >= sample_rate / 2.0:
+        raise ValueError("Benchmark offset must be within half the sample rate.")
+    if center_freq is None:
+        center_freq = 400_000_000.0 if target_freq is None else target_freq - freq_offset
+    if target_freq is None:
+        target_freq = center_freq + freq_offset
+    kwargs = dict(base_kwargs or {})
+    for k in ("in_path", "target_freq", "center_freq", "output_path"):
+        kwargs.pop(k, None)
+    with tempfile.TemporaryDirectory(prefix="iq_bench_") as tmp:
+        wav = Path(tmp) / "synthetic_iq.wav"
+        out = Path(tmp) / "benchmark_audio.wav"
+        _generate_synthetic_iq(wav, sample_rate, seconds, freq_offset)
+        config = ProcessingConfig(in_path=wav, target_freq=float(target_freq), center_freq=float(center_freq),
+                                  output_path=out, **kwargs)
+        t0 = time.perf_counter()
+        ProcessingPipeline(config).run(progress_sink=None)
+        elapsed = time.perf_counter() - t0
+    n = int(round(sample_rate * seconds))
+    LOG.info("Benchmark processed %d IQ samples in %.3f s (%.2fx realtime).", n, elapsed,
+             seconds / elapsed if elapsed > 0 else float("inf"))
+    return 0

@@ -1,0 +1,84 @@
+// stages.hip -- stand-alone NCO mixer stage + library plumbing (errors, version).
+//
+// Replaces reference src/iq_to_audio/processing.py:289-297 (ComplexOscillator.mix) for
+// callers that use the pluggable stages one at a time.  The fused path
+// (channelize.hip) never materialises the mixed stream; this kernel exists so that the
+// stage API is complete and so that the fused path can be checked stage by stage.
+#include "common.h"
+
+#include <cstring>
+
+namespace iqa {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <int FMT>
+__global__ void k_oscillator_mix(const void *in, long long n, int iq_order, double phase0, double step, float2 *out)
+{
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a, b;
+    if constexpr (FMT == IQA_FMT_S16) {
+        const int v = reinterpret_cast<const int *>(in)[i];
+        a = static_cast<float>(static_cast<short>(v & 0xffff)) * (1.0f / 32768.0f);
+        b = static_cast<float>(v >> 16) * (1.0f / 32768.0f);
+    } else if constexpr (FMT == IQA_FMT_U8) {
+        const unsigned short v = reinterpret_cast<const unsigned short *>(in)[i];
+        a = (static_cast<float>(v & 0xff) - 128.0f) * (1.0f / 128.0f);
+        b = (static_cast<float>(v >> 8) - 128.0f) * (1.0f / 128.0f);
+    } else {
+        const float2 v = reinterpret_cast<const float2 *>(in)[i];
+        a = v.x;
+        b = v.y;
+    }
+    // IQReader._extract_iq (processing.py:268-279): even/odd -> I/Q, optional swap, optional -Q
+    float xr = (iq_order & 1) ? b : a;
+    float xi = (iq_order & 1) ? a : b;
+    if (iq_order & 2) xi = -xi;
+    // float64 phase ramp phase0 + step*i, oscillator rounded to complex64, complex64 product
+    const double ph = fma(step, static_cast<double>(i), phase0);
+    double s, c;
+    sincos(ph, &s, &c);
+    const float cf = static_cast<float>(c), sf = static_cast<float>(s);
+    out[i] = make_float2(xr * cf - xi * sf, xr * sf + xi * cf);
+}
+
+}  // namespace iqa
+
+using namespace iqa;
+
+extern "C" int iqa_abi_version(void) { return IQA_ABI_VERSION; }
+
+extern "C" const char *iqa_last_error(void) { return g_err; }
+
+extern "C" int iqa_oscillator_mix(int32_t fmt, int32_t iq_order, const void *in_dev, int64_t n, double phase0,
+                                  double step, void *out_dev, void *stream)
+{
+    if (frame_bytes(fmt) == 0) return fail_inval("unknown sample format");
+    if (iq_order < 0 || iq_order > 3) return fail_inval("Unsupported iq_order");
+    if (n < 0) return fail_inval("negative length");
+    if (n == 0) return IQA_OK;
+    if (!in_dev || !out_dev) return fail_inval("NULL device pointer");
+    dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+    hipStream_t s = as_stream(stream);
+    switch (fmt) {
+        case IQA_FMT_S16:
+            hipLaunchKernelGGL(k_oscillator_mix<IQA_FMT_S16>, grid, block, 0, s, in_dev, (long long)n, (int)iq_order, phase0, step, static_cast<float2 *>(out_dev));
+            break;
+        case IQA_FMT_U8:
+            hipLaunchKernelGGL(k_oscillator_mix<IQA_FMT_U8>, grid, block, 0, s, in_dev, (long long)n, (int)iq_order, phase0, step, static_cast<float2 *>(out_dev));
+            break;
+        default:
+            hipLaunchKernelGGL(k_oscillator_mix<IQA_FMT_F32>, grid, block, 0, s, in_dev, (long long)n, (int)iq_order, phase0, step, static_cast<float2 *>(out_dev));
+            break;
+    }
+    return check_launch("k_oscillator_mix");
+}

@@ -1,0 +1,228 @@
+"""Host-side planning for the hot path (float64 / exact-integer scalar logic, no device work).
+
+Mirrors the scalar rules of the reference's ``processing.py`` (chunk tuning, decimation
+choice, Kaiser channel filter) and adds what the fused GPU channelizer needs: complex
+taps pre-rotated by the NCO, the 64-bit fixed-point output rotation, and the folding
+of ``iq_order`` into taps/flags so that the kernel's inner loop is a plain dot product.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from fractions import Fraction
+
+import numpy as np
+
+MAX_CHUNK = 4_194_304
+TWO64 = 1 << 64
+IQ_ORDERS = ("iq", "qi", "iq_inv", "qi_inv")
+INGEST_SCALE = {"s16": 1.0 / 32768.0, "u8": 1.0 / 128.0, "f32": 1.0}
+FMT_CODE = {"s16": 0, "u8": 1, "f32": 2}
+FMT_NUMPY = {"s16": np.int16, "u8": np.uint8, "f32": np.float32}
+
+
+def tune_chunk_size(sample_rate: float, requested: int) -> int:
+    """Effective chunk length (reference processing.py:65-81).
+
+    The result is *semantic*, not a memory knob here: it fixes where the SSB AGC gain
+    restarts and which prefix ``choose_mix_sign`` inspects.
+    """
+    base = max(1, requested)
+    if sample_rate <= 0:
+        return base
+    target_seconds = 0.25
+    if sample_rate >= 2_000_000.0:
+        target_seconds = 0.40
+    if sample_rate >= 5_000_000.0:
+        target_seconds = 0.50
+    desired = int(round(sample_rate * target_seconds))
+    if desired <= base:
+        return base
+    desired = min(MAX_CHUNK, max(base, desired))
+    return int(min(max(1 << math.ceil(math.log2(desired)), base), MAX_CHUNK))
+
+
+def choose_decimation(sample_rate: float, fs_ch_target: float) -> tuple[int, float]:
+    """(D, fs_channel) (reference processing.py:885-890; Python round = half-to-even)."""
+    decimation = max(1, int(round(sample_rate / fs_ch_target)))
+    fs_channel = sample_rate / decimation
+    if fs_channel > fs_ch_target * 1.5:
+        decimation = max(int(math.floor(sample_rate / fs_ch_target)), 1)
+        fs_channel = sample_rate / decimation
+    return decimation, fs_channel
+
+
+def kaiser_beta(atten_db: float) -> float:
+    """Kaiser's empirical beta(A) formula (what scipy.signal.kaiser_beta evaluates)."""
+    a = abs(atten_db)
+    if a > 50:
+        return 0.1102 * (a - 8.7)
+    if a > 21:
+        return 0.5842 * (a - 21) ** 0.4 + 0.07886 * (a - 21)
+    return 0.0
+
+
+def design_channel_filter(sample_rate: float, bandwidth: float, decimation: int) -> np.ndarray:
+    """Kaiser-windowed low-pass, float64, unity DC gain (reference processing.py:599-620).
+
+    Same design rule as the reference (taps = clip(4*fs/max(1000, bw/2), 1024, 32768) made
+    odd; cutoff = min(0.525*bw, 0.9*fs/(2D)); 80 dB Kaiser), evaluated directly with NumPy:
+    h[n] = 2fc/fs * sinc(2fc/fs * (n - (N-1)/2)) * kaiser(N, beta), normalised to sum 1 --
+    the windowed-sinc construction scipy.signal.firwin documents for a single low-pass band.
+    """
+    guard = max(1_000.0, bandwidth * 0.5)
+    cutoff = min(bandwidth * 0.5 * 1.05, (sample_rate / (2.0 * max(decimation, 1))) * 0.9)
+    if cutoff <= 0:
+        raise ValueError("Invalid cutoff frequency for channel filter.")
+    width = guard / sample_rate
+    num_taps = int(np.clip(4.0 / max(width, 1e-8), 1024, 32768))
+    if num_taps % 2 == 0:
+        num_taps += 1
+    beta = kaiser_beta(80.0)
+    fc = cutoff / (0.5 * sample_rate)  # relative to Nyquist
+    m = np.arange(num_taps, dtype=np.float64) - (num_taps - 1) / 2.0
+    h = fc * np.sinc(fc * m) * np.kaiser(num_taps, beta)
+    return np.asarray(h / h.sum(), dtype=np.float64)
+
+
+def freq_ratio_turns(freq_offset: float, sample_rate: float, sign: int) -> int:
+    """NCO phase advance per input sample as a 64-bit fraction of a turn.
+
+    The reference mixes with exp(j*sign*inc*n), inc = -2*pi*f_off/fs (processing.py:287,293),
+    i.e. -sign*f_off/fs turns per sample.  Floats are exact rationals, so the ratio is
+    formed exactly and rounded once to 2^-64 turn.
+    """
+    theta = -sign * Fraction(freq_offset) / Fraction(sample_rate)
+    theta -= math.floor(theta)
+    return int(round(theta * TWO64)) % TWO64
+
+
+@dataclass
+class ChannelPlan:
+    """Everything the fused channelizer kernel needs for one channel."""
+
+    fmt: str
+    ntaps: int
+    decimation: int
+    taps_window: np.ndarray  # complex64 [Lpad], window order, ingest scale folded in
+    conj_sum: int
+    rotate: int
+    rot_step: int
+    rot_base: int
+    out_scale: complex
+
+
+def plan_channel(
+    taps: np.ndarray,
+    *,
+    sample_rate: float,
+    freq_offset: float,
+    mix_sign: int,
+    decimation: int,
+    fmt: str = "s16",
+    iq_order: str = "iq",
+    padded_len: int | None = None,
+) -> ChannelPlan:
+    """Fold NCO + iq_order + ingest scale into complex taps and output-rotation constants.
+
+    mix -> filter -> decimate of the reference equals
+        z[m] = e^{-j 2 pi theta m D} * sum_k (h[k] e^{+j 2 pi theta k}) x[mD - k],
+    theta = -sign*f_off/fs turns/sample ... with the sign convention below:
+    the mixer multiplies sample n by e^{+j 2 pi W n / 2^64}; pulling e^{+j 2 pi W (mD)}
+    out of the sum leaves taps g[k] = h[k] e^{-j 2 pi W k / 2^64}.
+    """
+    if iq_order not in IQ_ORDERS:
+        raise ValueError(f"Unsupported iq_order '{iq_order}'")
+    if fmt not in FMT_CODE:
+        raise ValueError(f"unsupported sample format {fmt!r}")
+    h = np.asarray(taps, dtype=np.float64)
+    ntaps = h.size
+    w = freq_ratio_turns(freq_offset, sample_rate, mix_sign)
+    k = np.arange(ntaps, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        ph = np.uint64(w) * k  # wraps mod 2^64 == mod one turn
+    turns = (ph >> np.uint64(11)).astype(np.float64) * (2.0**-53)
+    g = h * np.exp(-2j * np.pi * turns)
+    # raw frame r = a + jb (a = first value of the pair).  x = c*r or c*conj(r):
+    #   iq: r | qi: j*conj(r) | iq_inv: conj(r) | qi_inv: -j*r      (IQReader._extract_iq)
+    conj = iq_order in ("qi", "iq_inv")
+    c = {"iq": 1.0 + 0j, "qi": 1j, "iq_inv": 1.0 + 0j, "qi_inv": -1j}[iq_order]
+    if conj:
+        g = np.conj(g)  # sum g*conj(r) = conj(sum conj(g)*r)
+    g = g * INGEST_SCALE[fmt]
+    lpad = padded_len if padded_len is not None else -(-ntaps // 256) * 256
+    win = np.zeros(lpad, dtype=np.complex64)
+    win[:ntaps] = g[::-1].astype(np.complex64)  # window order: win[i] multiplies x[n0-(L-1)+i]
+    return ChannelPlan(
+        fmt=fmt, ntaps=ntaps, decimation=int(decimation), taps_window=win, conj_sum=int(conj), rotate=1,
+        rot_step=(w * int(decimation)) % TWO64, rot_base=0, out_scale=c,
+    )
+
+
+def plan_plain_fir(taps: np.ndarray, padded_len: int | None = None) -> ChannelPlan:
+    """Real taps, complex64 in/out, no decimation, no rotation (the OverlapSaveFIR stage)."""
+    h = np.asarray(taps, dtype=np.float64)
+    lpad = padded_len if padded_len is not None else -(-h.size // 256) * 256
+    win = np.zeros(lpad, dtype=np.complex64)
+    win[: h.size] = h[::-1].astype(np.complex64)
+    return ChannelPlan("f32", h.size, 1, win, 0, 0, 0, 0, 1.0 + 0j)
+
+
+def chunk_output_starts(chunk: int, decimation: int, first_frame: int, n_frames: int) -> np.ndarray:
+    """Indices (relative to the first output of the block) of the first decimated sample of
+    every reference chunk that starts inside frames [first_frame, first_frame+n_frames).
+
+    ``first_frame`` must be a multiple of ``chunk``.  These are the points where the SSB AGC
+    gain restarts (decoders/ssb.py:72) and where per-chunk statistics are cut.
+    """
+    if first_frame % chunk:
+        raise ValueError("blocks must start on a chunk boundary")
+    d = decimation
+    m_first = -(-first_frame // d)
+    starts = np.arange(first_frame, first_frame + n_frames, chunk, dtype=np.int64)
+    return (-(-starts // d) - m_first).astype(np.int64)
+
+
+# ---- 48 kHz resampler plan (build-defined spec; see DESIGN.md "48 kHz stage") -----------------
+
+RS_ZERO_CROSSINGS = 16
+RS_CUTOFF = 0.97
+RS_KAISER_BETA = 9.0
+RS_OUT_RATE = 48_000
+
+
+@dataclass
+class ResamplerPlan:
+    in_rate: int
+    up: int
+    down: int
+    half_taps: int  # T: table rows hold taps t = -T..T
+    table: np.ndarray  # float64 [up, 2T+1]
+
+    def n_out(self, n_in: int) -> int:
+        return -(-n_in * self.up // self.down)
+
+
+def plan_resampler(fs_channel: float, out_rate: int = RS_OUT_RATE) -> ResamplerPlan:
+    """Polyphase table of the zero-phase Kaiser-sinc prototype.
+
+    The declared input rate is round(fs_channel), exactly what the reference tells ffmpeg
+    (processing.py:389-397).  Prototype (common rate up*in_rate): h[i] = sinc(0.97*i/M) *
+    kaiser(beta=9) over |i| <= 16*M, M = max(up, down), scaled to sum(h) = up.
+    Row p of the table holds h[p + t*up] for t = -T..T (zero outside the support).
+    """
+    rin = max(1, int(round(fs_channel)))
+    g = math.gcd(out_rate, rin)
+    up, down = out_rate // g, rin // g
+    m = max(up, down)
+    half = RS_ZERO_CROSSINGS * m
+    i = np.arange(-half, half + 1, dtype=np.float64)
+    u = i / half
+    win = np.i0(RS_KAISER_BETA * np.sqrt(np.clip(1.0 - u * u, 0.0, 1.0))) / np.i0(RS_KAISER_BETA)
+    h = np.sinc(RS_CUTOFF * i / m) * win
+    h *= up / h.sum()
+    t_half = -(-half // up)
+    idx = np.arange(up, dtype=np.int64)[:, None] + np.arange(-t_half, t_half + 1, dtype=np.int64)[None, :] * up
+    ok = np.abs(idx) <= half
+    table = np.where(ok, h[np.clip(idx + half, 0, 2 * half)], 0.0)
+    return ResamplerPlan(rin, up, down, int(t_half), np.ascontiguousarray(table, dtype=np.float64))

@@ -1,0 +1,656 @@
+"""GPU stand-in for the reference's ``src/iq_to_audio/processing.py`` DSP surface.
+
+Same names, arguments, state attributes and error behaviour as the reference classes
+(cited per class), with all arithmetic in the HIP library (``libiqa_hotpath.so``):
+
+    ProcessingConfig / ProcessingPipeline / ProcessingResult / ProcessingCancelled
+    ComplexOscillator, OverlapSaveFIR, Decimator, design_channel_filter,
+    choose_mix_sign, tune_chunk_size
+
+plus :class:`Channelizer`, the fused ingest+mix+filter+decimate stage the pipeline
+actually runs (one pass over the raw int16/u8/f32 capture in HBM).
+
+Stage methods accept either NumPy arrays (NumPy comes back, like the reference) or
+device tensors (device tensors come back -- no host round trip).  There is no CPU path:
+without a GPU or without the built library every stage raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import contextlib
+import logging
+import math
+from ctypes import byref, c_double, c_int32, c_int64, c_void_p
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from . import _dev as D
+from . import _native as N
+from . import dsp_plan as P
+from . import iqio
+from .decoders import create_decoder
+from .dsp_plan import design_channel_filter, tune_chunk_size  # noqa: F401  (re-exported API)
+from .progress import PhaseState, ProgressSink, ProgressTracker
+
+LOG = logging.getLogger(__name__)
+
+
+@dataclass
+class ProcessingConfig:
+    """Identical field set and defaults to the reference (processing.py:38-62).
+    ``fft_workers`` is accepted and ignored (there is no FFT on this path)."""
+
+    in_path: Path
+    target_freq: float = 0.0
+    bandwidth: float = 12_500.0
+    center_freq: float | None = None
+    center_freq_source: str | None = None
+    demod_mode: str = "nfm"
+    fs_ch_target: float = 96_000.0
+    deemph_us: float = 300.0
+    agc_enabled: bool = True
+    output_path: Path | None = None
+    dump_iq_path: Path | None = None
+    chunk_size: int = 1_048_576
+    filter_block: int = 65_536
+    iq_order: str = "iq"
+    probe_only: bool = False
+    mix_sign_override: int | None = None
+    plot_stages_path: Path | None = None
+    fft_workers: int | None = None
+    max_input_seconds: float | None = None
+    input_container: str | None = None
+    input_format: str | None = None
+    input_format_source: str | None = None
+    input_sample_rate: float | None = None
+
+
+@dataclass
+class SampleRateProbe:
+    """Where the sample rate came from (reference probe.py SampleRateProbe; only the header
+    parse exists here -- no ffprobe / libsndfile)."""
+
+    ffprobe: float | None = None
+    header: float | None = None
+    wave: float | None = None
+
+    @property
+    def value(self) -> float:
+        for v in (self.ffprobe, self.header, self.wave):
+            if v:
+                return float(v)
+        raise RuntimeError("Unable to determine sample rate.")
+
+
+def _size(x) -> int:
+    return int(x.numel()) if D.is_tensor(x) else int(np.asarray(x).size)
+
+
+def _as_frames(raw, fmt: str):
+    """(device tensor, n_frames) for raw capture frames: int16/uint8 interleaved pairs, or
+    float32 pairs / complex64 for 'f32' (both are the same bytes)."""
+    if fmt == "f32":
+        is_c = raw.is_complex() if D.is_tensor(raw) else np.iscomplexobj(raw)
+        if is_c:
+            x = D.to_device(raw, "complex64")
+            return x, int(x.numel())
+        x = D.to_device(raw, "float32").reshape(-1)
+        return x, int(x.numel()) // 2
+    x = D.to_device(raw, {"s16": "int16", "u8": "uint8"}[fmt]).reshape(-1)
+    return x, int(x.numel()) // 2
+
+
+# --------------------------------------------------------------------------------------------- #
+# pluggable stages                                                                              #
+# --------------------------------------------------------------------------------------------- #
+
+
+class ComplexOscillator:
+    """Continuous complex exponential for frequency translation (reference processing.py:282-297).
+
+    ``phase`` (radians) and ``increment`` are host floats exactly as in the reference; the
+    float64 ramp ``phase + sign*increment*n`` is evaluated per sample on the GPU.
+    ``fmt``/``iq_order`` let the stage also do the ingest convert when fed raw frames.
+    """
+
+    def __init__(self, freq_offset_hz: float, sample_rate: float):
+        self.phase = 0.0
+        self.increment = -2.0 * np.pi * freq_offset_hz / sample_rate
+
+    def mix(self, samples, sign: int, *, fmt: str = "f32", iq_order: str = "iq"):
+        if _size(samples) == 0:
+            return samples
+        if iq_order not in N.ORDER:
+            raise ValueError(f"Unsupported iq_order '{iq_order}'")
+        if fmt == "f32":
+            x = D.to_device(samples, "complex64")
+            n = x.numel()
+        else:
+            x = D.to_device(samples, {"s16": "int16", "u8": "uint8"}[fmt]).reshape(-1)
+            n = x.numel() // 2
+        out = D.empty(n, "complex64")
+        step = sign * self.increment
+        N.call("iqa_oscillator_mix", c_int32(P.FMT_CODE[fmt]), c_int32(N.ORDER[iq_order]), N.ptr(x), c_int64(n),
+               c_double(self.phase), c_double(step), N.ptr(out), N.stream_ptr())
+        self.phase = (self.phase + step * n) % (2.0 * np.pi)
+        return D.like_input(out, samples)
+
+
+class _ChannelKernel:
+    """Shared launcher for the fused channelizer kernel (``iqa_channelize``)."""
+
+    def __init__(self, plan: P.ChannelPlan):
+        self.plan = plan
+        lpad = int(N.lib().iqa_taps_padded_len(plan.ntaps))
+        if plan.taps_window.size != lpad:
+            raise ValueError("tap window padding does not match the library")
+        self.taps_dev = D.from_numpy(plan.taps_window)
+        self.params = N.ChanParams(
+            fmt=P.FMT_CODE[plan.fmt], ntaps=plan.ntaps, decimation=plan.decimation, conj_sum=plan.conj_sum,
+            rotate=plan.rotate, reserved=0, rot_step=plan.rot_step, rot_base=plan.rot_base,
+            out_scale_re=float(np.real(plan.out_scale)), out_scale_im=float(np.imag(plan.out_scale)),
+        )
+
+    def run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev=None):
+        if out_dev is None:
+            out_dev = D.empty(n_out, "complex64")
+        N.call("iqa_channelize", byref(self.params), N.ptr(self.taps_dev), N.ptr(raw_dev), c_int64(n_frames),
+               c_int64(consumed), N.ptr(hist_dev), c_int64(m_first), c_int64(n_out), N.ptr(out_dev), N.stream_ptr())
+        return out_dev
+
+
+class OverlapSaveFIR:
+    """Streaming channel filter stage (reference processing.py:300-346).
+
+    Same constructor, attributes (``taps``, ``filter_len``, ``overlap``, ``block_size``,
+    ``fft_size``, ``state``) and semantics -- causal linear convolution, zero initial state,
+    output length == input length, history of the last L-1 input samples carried across
+    calls -- but evaluated as a direct time-domain dot product on the GPU: ``block_size``
+    and ``fft_size`` are kept for API compatibility and do not affect the result.
+    """
+
+    def __init__(self, taps: np.ndarray, block_size: int, *, workers: int | None = None):
+        if block_size <= 0:
+            raise ValueError("block_size must be positive")
+        self.taps = np.asarray(taps).astype(np.complex128)
+        self.filter_len = len(taps)
+        self.overlap = self.filter_len - 1
+        self.block_size = block_size
+        self.fft_size = 1 << math.ceil(math.log2(self.block_size + self.filter_len - 1))
+        self.workers = None
+        self._kernel = None
+        self._real_taps = np.asarray(taps, dtype=np.float64)
+        self._hist = None  # device complex64[L-1]
+        self._consumed = 0
+
+    @property
+    def state(self) -> np.ndarray:
+        if self._hist is None:
+            return np.zeros(self.overlap, dtype=np.complex64)
+        return self._hist.cpu().numpy()
+
+    def process(self, samples):
+        if _size(samples) == 0:
+            return samples
+        if self._kernel is None:
+            self._kernel = _ChannelKernel(P.plan_plain_fir(self._real_taps))
+        x = D.to_device(samples, "complex64")
+        n = x.numel()
+        y = self._kernel.run(x, n, self._consumed, self._hist, self._consumed, n)
+        if self.overlap:
+            nxt = D.empty(self.overlap, "complex64")
+            N.call("iqa_history_update", c_int32(P.FMT_CODE["f32"]), c_int32(self.filter_len), N.ptr(self._hist),
+                   N.ptr(x), c_int64(n), N.ptr(nxt), N.stream_ptr())
+            self._hist = nxt
+        self._consumed += n
+        return D.like_input(y, samples)
+
+
+class Decimator:
+    """Keep global sample indices 0, D, 2D, ... across calls (reference processing.py:349-360)."""
+
+    def __init__(self, factor: int):
+        self.factor = max(1, factor)
+        self.offset = 0
+
+    def process(self, samples):
+        n = _size(samples)
+        if self.factor == 1 or n == 0:
+            return samples
+        start = (-self.offset) % self.factor
+        self.offset = (self.offset + n) % self.factor
+        n_out = 0 if start >= n else -(-(n - start) // self.factor)
+        x = D.to_device(samples, "complex64")
+        out = D.empty(n_out, "complex64")
+        N.call("iqa_decimate", N.ptr(x), c_int64(n), c_int64(start), c_int32(self.factor), N.ptr(out), c_int64(n_out),
+               N.stream_ptr())
+        return D.like_input(out, samples)
+
+
+class Channelizer:
+    """Fused ingest + NCO mix + channel FIR + decimate over raw capture frames.
+
+    Equivalent to ``Decimator(D).process(OverlapSaveFIR(taps, B).process(
+    ComplexOscillator(f_off, fs).mix(ingest(raw), sign)))`` of the reference
+    (processing.py:1088-1096) with the streaming state of all three carried across calls,
+    computed in one kernel that reads each raw frame (4 bytes for int16 I/Q) from HBM and
+    writes only the decimated complex64 stream.
+    """
+
+    def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, mix_sign: int, decimation: int,
+                 fmt: str = "s16", iq_order: str = "iq"):
+        lpad = int(N.lib().iqa_taps_padded_len(len(taps)))
+        self.plan = P.plan_channel(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
+                                   decimation=decimation, fmt=fmt, iq_order=iq_order, padded_len=lpad)
+        self._kernel = _ChannelKernel(self.plan)
+        self.fmt = fmt
+        self.decimation = int(decimation)
+        self.ntaps = len(taps)
+        self.consumed = 0  # frames seen so far (global index of the next frame)
+        self._hist = None  # device raw frames [L-1], same fmt
+
+    def outputs_for(self, n_frames: int) -> tuple[int, int]:
+        """(m_first, n_out) for a block of ``n_frames`` frames appended now."""
+        d = self.decimation
+        m_first = -(-self.consumed // d)
+        m_end = -(-(self.consumed + n_frames) // d)
+        return m_first, m_end - m_first
+
+    def process(self, raw, out_dev=None):
+        """``raw``: interleaved frames (NumPy or device tensor, dtype of ``fmt``; complex64 for f32).
+        Returns the decimated complex64 samples for this block."""
+        x, n = _as_frames(raw, self.fmt)
+        if n == 0:
+            return D.like_input(D.empty(0, "complex64"), raw)
+        m_first, n_out = self.outputs_for(n)
+        z = self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev) if n_out else D.empty(0, "complex64")
+        keep = self.ntaps - 1
+        if keep:
+            nxt = D.empty(keep * iqio.FRAME_BYTES[self.fmt], "uint8")
+            N.call("iqa_history_update", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.ntaps), N.ptr(self._hist),
+                   N.ptr(x), c_int64(n), N.ptr(nxt), N.stream_ptr())
+            self._hist = nxt
+        self.consumed += n
+        return D.like_input(z, raw)
+
+
+def _mean_power(z_dev, skip: int) -> float:
+    out = D.zeros(1, "float64")
+    N.call("iqa_mean_power", N.ptr(z_dev), c_int64(z_dev.numel()), c_int64(skip), N.ptr(out), N.stream_ptr())
+    return float(out.item())
+
+
+def choose_mix_sign(warmup, sample_rate: float, freq_offset: float, taps: np.ndarray, decimation: int, *,
+                    fmt: str = "f32", iq_order: str = "iq") -> int:
+    """Pick the mixer sign that puts more power in the channel (reference processing.py:623-663).
+
+    For each sign the first ``min(len, max(0.05*fs, 4L, 131072))`` samples are mixed, filtered
+    from zero state, decimated (``[::D]``) and the mean power after dropping the first
+    ``min(L, n/4)`` decimated samples is compared; strictly greater wins, ties give +1.
+    ``warmup`` is complex64 (NumPy / tensor) or raw frames when ``fmt`` is 's16'/'u8'.
+    """
+    x_all, n_in = _as_frames(warmup, fmt)
+    if n_in == 0:
+        return 1
+    ntaps = len(taps)
+    max_len = max(int(sample_rate * 0.05), ntaps * 4, 131_072)
+    snippet_len = min(n_in, max_len)
+    if snippet_len < ntaps:
+        snippet_len = min(n_in, ntaps * 2)
+    x = x_all[:snippet_len] if x_all.is_complex() else x_all[: 2 * snippet_len]
+    decim = max(decimation, 1)
+    best_sign, best_power = 1, -np.inf
+    for sign in (1, -1):
+        ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
+                         fmt=fmt, iq_order=iq_order)
+        z = ch.process(x)
+        if z.numel() == 0:
+            power = -np.inf
+        else:
+            discard = min(ntaps, z.numel() // 4)
+            if z.numel() - discard == 0:
+                discard = 0
+            power = _mean_power(z, discard)
+        if power > best_power:
+            best_power, best_sign = power, sign
+    return best_sign
+
+
+# --------------------------------------------------------------------------------------------- #
+# pipeline                                                                                      #
+# --------------------------------------------------------------------------------------------- #
+
+
+@dataclass
+class ProcessingResult:
+    """reference processing.py:666-675"""
+
+    sample_rate_probe: SampleRateProbe
+    center_freq: float
+    target_freq: float
+    freq_offset: float
+    decimation: int
+    fs_channel: float
+    mix_sign: int
+    audio_peak: float
+
+
+class ProcessingCancelled(RuntimeError):  # noqa: N818
+    """Raised when processing is aborted early by user request (reference processing.py:678)."""
+
+
+class ChannelDemod:
+    """Demodulate many reference chunks in one call while keeping per-chunk semantics.
+
+    Wraps a decoder from :func:`create_decoder`; the only per-chunk behaviour of the
+    reference decoders is the SSB AGC restart (decoders/ssb.py:72), expressed as restart
+    indices of the segmented scan.  Also applies AudioWriter's peak/clip
+    (processing.py:440-456) and collects per-chunk sum-of-squares for the rms_dbfs log.
+    """
+
+    def __init__(self, mode: str, fs_channel: float, *, deemph_us: float, agc_enabled: bool):
+        self.decoder = create_decoder(mode, deemph_us=deemph_us, agc_enabled=agc_enabled)
+        self.decoder.setup(fs_channel)
+        self.peak_dev = D.zeros(1, "float32")
+        self.chunk_sumsq: list = []  # (device float64[n_chunks], counts list)
+
+    def process(self, z_dev, chunk_starts: np.ndarray, out_dev):
+        """z_dev -> clipped float32 audio written into ``out_dev`` (len == len(z_dev))."""
+        n = int(z_dev.numel())
+        if n == 0:
+            return
+        starts_dev = D.from_numpy(np.ascontiguousarray(chunk_starts, dtype=np.int64))
+        from .decoders.ssb import SSBDecoder
+
+        if isinstance(self.decoder, SSBDecoder):
+            audio = self._process_ssb(z_dev, starts_dev)
+        else:
+            audio = self._process_plain(z_dev)
+        sumsq = D.zeros(len(chunk_starts), "float64")
+        N.call("iqa_writer_clip", N.ptr(audio), c_int64(n), N.ptr(self.peak_dev), N.ptr(starts_dev),
+               c_int64(len(chunk_starts)), N.ptr(sumsq), N.ptr(out_dev), N.stream_ptr())
+        counts = np.diff(np.append(chunk_starts, n))
+        self.chunk_sumsq.append((sumsq, counts))
+
+    def _process_plain(self, z_dev):
+        d = self.decoder
+        from .decoders.nfm import NarrowbandFMDecoder
+
+        if isinstance(d, NarrowbandFMDecoder):
+            return d._deemph.process(d._demod.process(z_dev))
+        env = D.empty(z_dev.numel(), "float32")
+        N.call("iqa_envelope", N.ptr(z_dev), c_int64(z_dev.numel()), N.ptr(env), N.stream_ptr())
+        return d._dc_blocker.process(env)
+
+    def _process_ssb(self, z_dev, starts_dev):
+        d = self.decoder
+        base = D.empty(z_dev.numel(), "float32")
+        N.call("iqa_real_part", N.ptr(z_dev), c_int64(z_dev.numel()), N.ptr(base), N.stream_ptr())
+        dc = d._dc_blocker.process(base)
+        return d._apply_agc(dc, starts_dev) if d._agc_enabled else dc
+
+    @property
+    def peak(self) -> float:
+        return float(self.peak_dev.item())
+
+    def chunk_rms_dbfs(self) -> list[float]:
+        out = []
+        for sumsq, counts in self.chunk_sumsq:
+            for s, c in zip(sumsq.cpu().numpy(), counts):
+                if c > 0:
+                    out.append(20.0 * math.log10(math.sqrt(float(s) / float(c) + 1e-18) + 1e-12))
+        return out
+
+
+class Resampler48k:
+    """The ``-ar 48000 -acodec pcm_s16le`` leg (reference processing.py:399-418) on the GPU.
+    Build-defined specification (dsp_plan.plan_resampler); parity with libswresample is unpinned."""
+
+    def __init__(self, fs_channel: float):
+        self.plan = P.plan_resampler(fs_channel)
+        self.table_dev = D.from_numpy(self.plan.table.reshape(-1))
+
+    def process(self, audio_dev):
+        n_in = int(audio_dev.numel())
+        n_out = self.plan.n_out(n_in)
+        y = D.empty(n_out, "float32")
+        if n_out:
+            N.call("iqa_resample", N.ptr(audio_dev), c_int64(n_in), N.ptr(self.table_dev), c_int32(self.plan.up),
+                   c_int32(self.plan.down), c_int32(self.plan.half_taps), c_int64(0), c_int64(n_out), N.ptr(y),
+                   N.stream_ptr())
+        return y
+
+    @staticmethod
+    def to_pcm16(y_dev):
+        pcm = D.empty(y_dev.numel(), "int16")
+        if y_dev.numel():
+            N.call("iqa_float_to_pcm16", N.ptr(y_dev), c_int64(y_dev.numel()), N.ptr(pcm), N.stream_ptr())
+        return pcm
+
+
+def _encode_iq_raw(samples: np.ndarray, codec: str) -> bytes:
+    """Pass-through slice encoding (reference processing.py _encode_iq_raw)."""
+    inter = np.empty(samples.size * 2, dtype=np.float32)
+    inter[0::2] = samples.real
+    inter[1::2] = samples.imag
+    if codec == "pcm_f32le":
+        return inter.astype("<f4").tobytes()
+    if codec == "pcm_s16le":
+        return (np.clip(inter, -1.0, 0.999969) * 32767.0).astype("<i2").tobytes()
+    if codec == "pcm_u8":
+        return np.round((np.clip(inter, -1.0, 1.0) + 1.0) * 127.5).astype(np.uint8).tobytes()
+    raise ValueError(f"Unsupported codec {codec}")
+
+
+class ProcessingPipeline:
+    """``ProcessingPipeline(config).run(progress_sink) -> ProcessingResult``, ``.cancel()``
+    (reference processing.py:682-1213).
+
+    Differences that are deliberate and documented in DESIGN.md: the capture is memory-mapped
+    and streamed to HBM in blocks of whole reference chunks (``block_chunks``); one kernel does
+    ingest+mix+filter+decimate; the 48 kHz resample/PCM16 encode runs on the GPU at the end;
+    no ffmpeg/ffprobe processes exist.  Per-chunk semantics (AGC restart points, mix-sign
+    warm-up window, sample counts) are the reference's.
+    """
+
+    #: frames per device block (rounded down to whole chunks); 64 Mi frames = 256 MiB of int16 I/Q
+    block_frames_target = 64 * 1024 * 1024
+
+    def __init__(self, config: ProcessingConfig):
+        self.config = config
+        self._cancelled = False
+        self._resolved_chunk_size: int | None = None
+        self.chunk_rms_dbfs: list[float] = []
+        self.audio_fs_channel = None  # device float32 tensor of the clipped channel-rate audio (kept for tests)
+        self.keep_channel_audio = False
+
+    def cancel(self) -> None:
+        self._cancelled = True
+
+    def _is_pass_through_mode(self) -> bool:
+        return (self.config.demod_mode or "").lower() in {"none", "pass", "iq"}
+
+    def _effective_chunk_size(self, sample_rate: float) -> int:
+        if self._resolved_chunk_size is None:
+            self._resolved_chunk_size = tune_chunk_size(sample_rate, self.config.chunk_size)
+        return self._resolved_chunk_size
+
+    def _default_output_path(self, info: iqio.CaptureInfo) -> Path:
+        ft = int(self.config.target_freq)
+        if self._is_pass_through_mode():
+            suffix = self.config.in_path.suffix
+            if info.container == "wav":
+                ext = suffix if suffix.lower() in {".wav", ".wave", ".wv", ".rf64"} else ".wav"
+            else:
+                ext = suffix or {"pcm_u8": ".cu8", "pcm_s16le": ".cs16", "pcm_f32le": ".cf32"}.get(info.codec, ".raw")
+            return self.config.in_path.with_name(f"slice_{ft}{ext}")
+        return self.config.in_path.with_name(f"audio_{ft}_48k.wav")
+
+    def run(self, progress_sink: ProgressSink | None = None) -> ProcessingResult:
+        cfg = self.config
+        tracker = ProgressTracker(progress_sink)
+        output_path: Path | None = None
+
+        def _request_cancel() -> None:
+            self._cancelled = True
+            tracker.cancel()
+            tracker.status("Cancelling…")
+
+        def _check_cancel(stage: str = "") -> None:
+            if self._cancelled or tracker.cancelled:
+                self._cancelled = True
+                LOG.info("Processing cancelled during %s.", stage or "run")
+                raise ProcessingCancelled("Processing cancelled by user.")
+
+        if progress_sink is not None:
+            with contextlib.suppress(AttributeError):
+                progress_sink.set_cancel_callback(_request_cancel)
+
+        manual_rate = cfg.input_sample_rate
+        if manual_rate is not None and manual_rate <= 0:
+            raise ValueError("Input sample rate override must be positive.")
+        try:
+            info = iqio.probe_capture(cfg.in_path, input_format=cfg.input_format, input_container=cfg.input_container,
+                                      input_sample_rate=manual_rate)
+            cfg.input_container = cfg.input_container or info.container
+            cfg.input_format = cfg.input_format or info.codec
+            if info.container == "raw" and manual_rate is None:
+                raise ValueError("Raw IQ inputs require --input-sample-rate (CLI) or a manual entry in the GUI.")
+            if info.sample_rate is None or info.sample_rate <= 0:
+                raise RuntimeError("Unable to determine input sample rate automatically. Provide --input-sample-rate.")
+            sample_rate = float(info.sample_rate)
+            probe = SampleRateProbe(header=None if manual_rate else sample_rate, wave=sample_rate)
+
+            preview_seconds = cfg.max_input_seconds
+            if preview_seconds is not None and preview_seconds <= 0:
+                preview_seconds = None
+            total = info.n_frames
+            if preview_seconds is not None:
+                total = min(total, max(1, int(math.floor(preview_seconds * sample_rate))))
+
+            if cfg.target_freq <= 0 and not cfg.probe_only:
+                raise ValueError("Target frequency must be positive. Provide --ft or use --interactive.")
+            if cfg.bandwidth <= 0:
+                raise ValueError("Bandwidth must be positive.")
+            center_freq = cfg.center_freq
+            if center_freq is None:
+                center_freq, source = iqio.center_frequency_from_filename(cfg.in_path)
+                if center_freq is None:
+                    raise ValueError(
+                        "Center frequency not supplied and could not be determined from metadata or filename. "
+                        "Use --fc to provide it explicitly.")
+                cfg.center_freq, cfg.center_freq_source = center_freq, source
+            target_freq = cfg.target_freq if cfg.target_freq > 0 else center_freq
+            freq_offset = target_freq - center_freq
+            decimation, fs_channel = P.choose_decimation(sample_rate, cfg.fs_ch_target)
+            chunk = self._effective_chunk_size(sample_rate)
+            pass_through = self._is_pass_through_mode()
+            LOG.info("Input sample rate %.2f Hz; centre %.0f Hz, target %.0f Hz, offset %.0f Hz; decimation %d -> %.2f Hz",
+                     sample_rate, center_freq, target_freq, freq_offset, decimation, fs_channel)
+
+            n_dec_est = total / max(decimation, 1)
+            phases = [PhaseState("ingest", "Ingest IQ", float(total)), PhaseState("channel", "Channelize", n_dec_est),
+                      PhaseState("demod", "Demodulate", n_dec_est),
+                      PhaseState("encode", "Encode Audio", total / sample_rate * 48_000.0)]
+            if cfg.dump_iq_path:
+                phases.insert(3, PhaseState("dump_iq", "Write IQ Dump", n_dec_est))
+            tracker.start(phases)
+            tracker.status("design filter")
+            _check_cancel("initialization")
+            taps = design_channel_filter(sample_rate, cfg.bandwidth, decimation)
+            LOG.info("Designed FIR channel filter with %d taps.", len(taps))
+            if cfg.filter_block <= 0:
+                raise ValueError("block_size must be positive")
+            if not pass_through:
+                demod = ChannelDemod(cfg.demod_mode, fs_channel, deemph_us=cfg.deemph_us, agc_enabled=cfg.agc_enabled)
+            if cfg.iq_order not in N.ORDER:
+                raise ValueError(f"Unsupported iq_order '{cfg.iq_order}'")
+            if total == 0:
+                raise RuntimeError("Input stream produced no samples.")
+
+            frames = iqio.map_frames(info)
+            torch = D.torch_mod()
+            np_dt = {"s16": "int16", "u8": "uint8", "f32": "float32"}[info.fmt]
+
+            def upload(lo: int, hi: int):
+                host = np.ascontiguousarray(frames[2 * lo : 2 * hi])
+                return torch.from_numpy(host).to(D.device(), non_blocking=False)
+
+            warm = upload(0, min(chunk, total))
+            _check_cancel("warm-up")
+            if cfg.mix_sign_override in (1, -1):
+                mix_sign = cfg.mix_sign_override
+            else:
+                mix_sign = choose_mix_sign(warm, sample_rate, freq_offset, taps, decimation, fmt=info.fmt,
+                                           iq_order=cfg.iq_order)
+            LOG.info("Selected mixer sign %d based on warm-up snippet.", mix_sign)
+            output_path = cfg.output_path if cfg.output_path else self._default_output_path(info)
+            if cfg.probe_only:
+                tracker.advance("ingest", float(warm.numel() // 2))
+                return ProcessingResult(probe, center_freq, target_freq, freq_offset, decimation, fs_channel, mix_sign, 0.0)
+
+            chan = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
+                               decimation=decimation, fmt=info.fmt, iq_order=cfg.iq_order)
+            n_dec_total = -(-total // decimation)
+            z_all = D.empty(n_dec_total, "complex64") if (pass_through or cfg.dump_iq_path) else None
+            audio_all = None if pass_through else D.empty(n_dec_total, "float32")
+            block = max(1, self.block_frames_target // chunk) * chunk
+            done = 0
+            pos_dec = 0
+            while done < total:
+                _check_cancel(f"block at frame {done}")
+                hi = min(done + block, total)
+                raw = warm if (done == 0 and hi <= warm.numel() // 2) else upload(done, hi)
+                n = hi - done
+                tracker.advance("ingest", float(n))
+                tracker.status(f"channel @ {done}")
+                m_first, n_out = chan.outputs_for(n)
+                z = chan.process(raw)
+                tracker.advance("channel", float(n_out))
+                if z_all is not None and n_out:
+                    z_all[pos_dec : pos_dec + n_out] = z
+                    if cfg.dump_iq_path:
+                        tracker.advance("dump_iq", float(n_out))
+                if not pass_through and n_out:
+                    starts = P.chunk_output_starts(chunk, decimation, done, n)
+                    demod.process(z, starts, audio_all[pos_dec : pos_dec + n_out])
+                tracker.advance("demod", float(n_out))
+                _check_cancel("encode")
+                tracker.advance("encode", n_out / max(fs_channel, 1e-9) * 48_000.0)
+                pos_dec += n_out
+                done = hi
+
+            tracker.status("flush outputs")
+            output_path.parent.mkdir(parents=True, exist_ok=True)
+            if cfg.dump_iq_path:
+                Path(cfg.dump_iq_path).write_bytes(z_all[:pos_dec].cpu().numpy().astype(np.complex64).tobytes())
+            if pass_through:
+                zs = z_all[:pos_dec].cpu().numpy()
+                peak = float(np.max(np.abs(zs))) if zs.size else 0.0
+                payload = _encode_iq_raw(zs, info.codec)
+                if info.container == "wav":
+                    arr = np.frombuffer(payload, dtype=iqio.NP_DTYPE[info.fmt])
+                    iqio.write_wav_iq(output_path, arr, int(round(fs_channel)), info.fmt)
+                else:
+                    output_path.write_bytes(payload)
+            else:
+                demod.decoder.finalize()
+                audio = audio_all[:pos_dec]
+                if self.keep_channel_audio:
+                    self.audio_fs_channel = audio
+                rs = Resampler48k(fs_channel)
+                pcm = rs.to_pcm16(rs.process(audio)).cpu().numpy()
+                iqio.write_wav_pcm16(output_path, pcm, 48_000)
+                peak = demod.peak
+                self.chunk_rms_dbfs = demod.chunk_rms_dbfs()
+                LOG.info("Audio peak level %.2f dBFS.", 20.0 * math.log10(max(peak, 1e-6)))
+            tracker.status("Processing complete")
+            return ProcessingResult(probe, center_freq, target_freq, freq_offset, decimation, fs_channel, mix_sign, peak)
+        except ProcessingCancelled:
+            if not cfg.probe_only and output_path:
+                with contextlib.suppress(OSError):
+                    output_path.unlink(missing_ok=True)
+            raise
+        finally:
+            tracker.close()
