@@ -101,6 +101,27 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
                    int64_t consumed, const void *hist_dev, int64_t m_first, int64_t n_out, void *z_out_dev,
                    void *stream);
 
+/*
+ * int8-MFMA form of iqa_channelize for int16 captures (same reference lines, same result up to the
+ * 16-bit fixed-point tap quantisation, ~1e-6 of full scale): the decimating FIR is evaluated as a
+ * dense integer GEMM on the matrix cores with exact int32 accumulation (see channelize_mfma.hip).
+ * It covers only outputs whose whole read range lies inside raw_dev[0, n_frames): columns
+ * (m_first-64)*D+1 ... ; the caller runs iqa_channelize for the few outputs at the block's head
+ * (history) and tail.  Requires ceil(ntaps/decimation) <= 64.
+ *   afrag_dev : tap fragments, iqa_mfma_afrag_bytes(D) bytes, layout [kstep][rowtile 4][piece 2][lane 64][16 B]
+ *               (host: dsp_plan.plan_mfma); unit/c_re/c_im from the same quantisation.
+ */
+typedef struct {
+    int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
+    int32_t reserved;
+    double unit;               /* value of one tap LSB (ingest scale folded in) */
+    double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
+} iqa_mfma_params;
+int64_t iqa_mfma_afrag_bytes(int32_t decimation);
+int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,
+                        const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first, int64_t n_out,
+                        void *z_out_dev, void *stream);
+
 /* Copy the last L-1 frames of (hist | raw) into hist (handles n_frames < L-1 by shifting).
  * ref: OverlapSaveFIR.process state update, processing.py:341-345.
  * hist_next_dev must not alias hist_dev. */

@@ -39,12 +39,22 @@ class ChanParams(ctypes.Structure):
     ]
 
 
+class MfmaParams(ctypes.Structure):
+    """``iqa_mfma_params`` (include/iqa_hotpath.h)."""
+
+    _fields_ = [("outputs_per_block", c_int32), ("reserved", c_int32), ("unit", c_double), ("c_re", c_double),
+                ("c_im", c_double)]
+
+
 _SIGNATURES = {
     "iqa_abi_version": (ctypes.c_int, []),
     "iqa_last_error": (ctypes.c_char_p, []),
     "iqa_taps_padded_len": (c_int64, [c_int32]),
     "iqa_channelize": (ctypes.c_int, [ctypes.POINTER(ChanParams), c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                       c_int64, c_int64, c_void_p, c_void_p]),
+    "iqa_mfma_afrag_bytes": (c_int64, [c_int32]),
+    "iqa_channelize_mfma": (ctypes.c_int, [ctypes.POINTER(ChanParams), ctypes.POINTER(MfmaParams), c_void_p, c_void_p,
+                                           c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "iqa_history_update": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "iqa_oscillator_mix": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_int64, c_double, c_double, c_void_p, c_void_p]),
     "iqa_decimate": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p]),

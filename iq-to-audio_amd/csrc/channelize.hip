@@ -118,7 +118,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const long long o_blk = static_cast<long long>(blockIdx.x) * CH_OUT_PER_BLOCK;
+    // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs (b and b+8 share an L2), and
+    // neighbouring output tiles re-read ~L/(32 D) of each other's window.  Give every XCD one
+    // contiguous eighth of the tiles so those re-reads hit its own L2 instead of HBM.
+    // (speed only: any placement computes the same outputs)
+    const unsigned nblk = gridDim.x, per = nblk >> 3;
+    unsigned tile = blockIdx.x;
+    if (tile < per * 8u) tile = (tile & 7u) * per + (tile >> 3);
+    const long long o_blk = static_cast<long long>(tile) * CH_OUT_PER_BLOCK;
     const long long o0 = o_blk + wave * CH_R;
 
     // window start (local frame index) of each of this wave's outputs
@@ -164,19 +171,36 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
                 }
             }
         } else {
+            // edge block (history / end of block / ragged tail): same loop, but each lane decides per
+            // 4-frame group whether it may use the vector load; only groups that straddle the block
+            // boundary fall back to guarded scalar loads.
             for (int it = lane * 4; it < cnt; it += kWave * 4) {
+                const float4 g01 = *reinterpret_cast<const float4 *>(&s_taps[it]);
+                const float4 g23 = *reinterpret_cast<const float4 *>(&s_taps[it + 2]);
+                const float gr[4] = {g01.x, g01.z, g23.x, g23.z};
+                const float gi[4] = {g01.y, g01.w, g23.y, g23.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float2 g = s_taps[it + j];
-                    if (tc + it + j >= a.L) continue;  // padded taps are zero; skip their frames entirely
+                for (int r = 0; r < CH_R; ++r) {
+                    if (o0 + r >= a.n_out) continue;
+                    const long long f = start[r] + tc + it;
+                    float xr[4], xi[4];
+                    if (f >= 0 && f + 4 <= a.n_frames) {
+                        load4<FMT>(a.raw, f, xr, xi);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < CH_R; ++r) {
-                        if (o0 + r >= a.n_out) continue;
-                        const float2 x = load_guarded<FMT>(a, start[r] + tc + it + j);
-                        acc_re[r] = fmaf(g.x, x.x, acc_re[r]);
-                        acc_re[r] = fmaf(-g.y, x.y, acc_re[r]);
-                        acc_im[r] = fmaf(g.x, x.y, acc_im[r]);
-                        acc_im[r] = fmaf(g.y, x.x, acc_im[r]);
+                        for (int j = 0; j < 4; ++j) {
+                            // padded taps are zero, but their frames may lie past the block: never touch them
+                            const float2 x = (tc + it + j < a.L) ? load_guarded<FMT>(a, f + j) : make_float2(0.f, 0.f);
+                            xr[j] = x.x;
+                            xi[j] = x.y;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc_re[r] = fmaf(gr[j], xr[j], acc_re[r]);
+                        acc_re[r] = fmaf(-gi[j], xi[j], acc_re[r]);
+                        acc_im[r] = fmaf(gr[j], xi[j], acc_im[r]);
+                        acc_im[r] = fmaf(gi[j], xr[j], acc_im[r]);
                     }
                 }
             }

@@ -1,0 +1,228 @@
+// channelize_mfma.hip -- int8-MFMA form of the fused ingest+mix+FIR+decimate kernel (gfx950).
+//
+// Same mathematics as channelize.hip (reference processing.py:268-279, 289-297, 325-346,
+// 354-360): z[m] = rot(m) * sum_k g[k] x[mD-k].  Here the decimating FIR is recast as a
+// dense integer GEMM so that it runs on the matrix cores at the int8 rate, with exact
+// integer accumulation:
+//
+//   rows of D frames:  X[b][kap] = v[2(bD+1) + kap],  kap in [0,2D)  (raw int16 I,Q,I,Q,... --
+//                      row b IS a contiguous run of the capture, rows are 2D values apart)
+//   tap rows:          W[q][rho] = g[qD-1-rho], q = 1..P (P = ceil(L/D) <= 64), real form
+//                      A[(re,q)][2rho]=Re, [2rho+1]=-Im ; A[(im,q)][2rho]=Im, [2rho+1]=Re
+//   GEMM:              G[row][b] = sum_kap A[row][kap] * X[b][kap]        (128 x Ncols x 2D)
+//   diagonal sum:      S[m] = sum_q G[(.,q)][m-q]
+//
+// int16 data are split exactly into bytes v = 256*hi + lo' + 128 (hi = v>>8, lo' = (v&255)-128,
+// both int8), taps are quantised to 16-bit fixed point T = 256*q1 + q2 (q1,q2 int8, one global
+// unit u), and three int8 MFMAs per (row tile, k step) accumulate
+//      ACC1 += q1*hi        ACC2 += q1*lo' + q2*hi        (q2*lo' dropped: < 1e-6 of full scale)
+// so that  S = u*(65536*S1 + 256*S2 + 128*sum(T)).  All accumulation up to S1/S2 is exact
+// int32 (|S1| <= 2^14 L, |S2| <= 2^15 L < 2^31 for L <= 32769), hence bit-reproducible.
+//
+// Mapping: block = 4 waves; a block owns `range` consecutive outputs and walks the
+// range+63 data columns that touch them in tiles of 32 columns, one tile per wave at a time.
+// Per k step (32 int8 along K) a wave issues 2 unaligned global_load_dwordx4 per lane for the
+// data fragment (straight from HBM/L2 -- no LDS staging: a row is contiguous memory), splits
+// hi/lo bytes with v_perm_b32, reads 8 tap fragments from LDS (pre-swizzled by the host into
+// fragment order, conflict-free ds_read_b128) and issues 12 v_mfma_i32_32x32x32_i8.
+// The G tile never leaves registers except as ds_add_u32 into the block's S1/S2 arrays
+// (address = lane part + immediate), which are converted, rotated and stored once at the end.
+//
+// Lane maps of v_mfma_i32_32x32x32_i8 were verified on hardware with probe/mfma_i8_probe.hip:
+//   A[row=l&31][k=16(l>>5)+j], B[k=16(l>>5)+j][col=l&31], C: col=l&31, row=(r&3)+8(r>>2)+4(l>>5).
+#include "common.h"
+
+namespace iqa {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef v4i_t v4i_a4 __attribute__((aligned(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+constexpr int MF_WAVES = 4;
+constexpr int MF_THREADS = MF_WAVES * kWave;
+constexpr int MF_Q = 64;          // q slots per output component (needs ceil(L/D) <= 64)
+constexpr int MF_ROWTILES = 4;    // 2 components x 64 q = 128 rows
+constexpr int MF_KSTEP_BYTES = MF_ROWTILES * 2 * 1024;  // tap fragments per k step
+
+struct MfmaArgs {
+    const v4i_t *afrag;  // [ksteps][rowtile 4][piece 2][lane 64] 16-byte tap fragments
+    const int *raw;      // capture frames as dwords (lo half = I, hi half = Q)
+    float2 *out;         // out[i] = z[m_lo + i]
+    long long consumed, m_lo, n_out;
+    int D, ksteps, range;
+    double unit, c_re, c_im;
+    int conj_sum, rotate;
+    unsigned long long rot_step, rot_base;
+    float sc_re, sc_im;
+};
+
+__global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+
+    const long long i0 = static_cast<long long>(blockIdx.x) * a.range;  // first output of this block (relative)
+    const int cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - i0));
+    const long long m0 = a.m_lo + i0;
+    const int tiles = (cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
+    const int acc_len = tiles * 32 + MF_Q + 4;
+
+    v4i_t *s_a = reinterpret_cast<v4i_t *>(smem);
+    int *s_acc = reinterpret_cast<int *>(smem + static_cast<size_t>(a.ksteps) * MF_KSTEP_BYTES);
+    // s_acc layout: [S1re | S1im | S2re | S2im], each acc_len ints
+    for (int i = tid; i < a.ksteps * (MF_KSTEP_BYTES / 16); i += MF_THREADS) s_a[i] = a.afrag[i];
+    for (int i = tid; i < 4 * acc_len; i += MF_THREADS) s_acc[i] = 0;
+    __syncthreads();
+
+    for (int t = wave; t < tiles; t += MF_WAVES) {
+        const long long b = m0 - MF_Q + t * 32 + col;               // this lane's data column (global row index)
+        const int *rowp = a.raw + (b * a.D + 1 - a.consumed) + 8 * h;  // dword index of kap = 16h
+        v16i_t acc1[MF_ROWTILES], acc2[MF_ROWTILES];
+#pragma unroll
+        for (int rt = 0; rt < MF_ROWTILES; ++rt) {
+            acc1[rt] = v16i_t{0};
+            acc2[rt] = v16i_t{0};
+        }
+        v4i_t d0 = *reinterpret_cast<const v4i_a4 *>(rowp);
+        v4i_t d1 = *reinterpret_cast<const v4i_a4 *>(rowp + 4);
+        for (int ks = 0; ks < a.ksteps; ++ks) {
+            // prefetch the next k step's data (the last iteration re-reads the current one: in bounds)
+            const int *nxt = rowp + 16 * ((ks + 1 < a.ksteps) ? ks + 1 : ks);
+            const v4i_t n0 = *reinterpret_cast<const v4i_a4 *>(nxt);
+            const v4i_t n1 = *reinterpret_cast<const v4i_a4 *>(nxt + 4);
+            // split the 16 int16 values into high bytes and (low bytes - 128)
+            v4i_t hi, lo;
+            hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
+            hi.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x07050301);
+            hi.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x07050301);
+            hi.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x07050301);
+            lo.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200) ^ 0x80808080;
+            lo.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x06040200) ^ 0x80808080;
+            lo.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200) ^ 0x80808080;
+            lo.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x06040200) ^ 0x80808080;
+            const v4i_t *fa = s_a + ks * (MF_KSTEP_BYTES / 16) + lane;
+#pragma unroll
+            for (int rt = 0; rt < MF_ROWTILES; ++rt) {
+                const v4i_t q1 = fa[(rt * 2 + 0) * 64];
+                const v4i_t q2 = fa[(rt * 2 + 1) * 64];
+                acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, hi, acc1[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, lo, acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q2, hi, acc2[rt], 0, 0, 0);
+            }
+            d0 = n0;
+            d1 = n1;
+        }
+        // diagonal scatter: row (comp, qidx) of column b adds into position col_local + qidx + 1
+        int *base = s_acc + (t * 32 + col + 4 * h + 1);
+#pragma unroll
+        for (int rt = 0; rt < MF_ROWTILES; ++rt) {
+            int *p1 = base + (rt >> 1) * acc_len + (rt & 1) * 32;  // S1re / S1im
+            int *p2 = p1 + 2 * acc_len;                            // S2re / S2im
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                atomicAdd(p1 + off, acc1[rt][r]);
+                atomicAdd(p2 + off, acc2[rt][r]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // emission: output m0+i sits at position 64+i
+    for (int i = tid; i < cnt; i += MF_THREADS) {
+        const int pos = MF_Q + i;
+        const double s1r = s_acc[pos], s1i = s_acc[acc_len + pos];
+        const double s2r = s_acc[2 * acc_len + pos], s2i = s_acc[3 * acc_len + pos];
+        float my_re = static_cast<float>((s1r * 65536.0 + s2r * 256.0 + a.c_re) * a.unit);
+        float my_im = static_cast<float>((s1i * 65536.0 + s2i * 256.0 + a.c_im) * a.unit);
+        if (a.conj_sum) my_im = -my_im;
+        float yr = my_re, yi = my_im;
+        if (a.rotate) {
+            const unsigned long long m = static_cast<unsigned long long>(m0 + i);
+            const unsigned long long ph = a.rot_base + m * a.rot_step;
+            const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
+            double s, c;
+            sincospi(2.0 * frac, &s, &c);
+            const float cf = static_cast<float>(c), sf = static_cast<float>(s);
+            yr = my_re * cf - my_im * sf;
+            yi = my_re * sf + my_im * cf;
+        }
+        a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+    }
+}
+
+}  // namespace iqa
+
+using namespace iqa;
+
+extern "C" int64_t iqa_mfma_afrag_bytes(int32_t decimation)
+{
+    if (decimation < 1) return 0;
+    const int64_t ksteps = (2 * static_cast<int64_t>(decimation) + 31) / 32;
+    return ksteps * MF_KSTEP_BYTES;
+}
+
+extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,
+                                   const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
+                                   int64_t n_out, void *z_out_dev, void *stream)
+{
+    if (p == nullptr || q == nullptr) return fail_inval("params is NULL");
+    if (p->fmt != IQA_FMT_S16) return fail_inval("the MFMA channelizer takes int16 captures only");
+    if (p->ntaps <= 0 || p->decimation < 1) return fail_inval("bad ntaps/decimation");
+    const int64_t D = p->decimation;
+    if ((static_cast<int64_t>(p->ntaps) + D - 1) / D > MF_Q) return fail_inval("ceil(ntaps/decimation) must be <= 64");
+    if (n_out < 0 || n_frames < 0 || consumed < 0 || m_first < 0) return fail_inval("negative size");
+    if (n_out == 0) return IQA_OK;
+    if (!afrag_dev || !raw_dev || !z_out_dev) return fail_inval("NULL device pointer");
+    const int ksteps = static_cast<int>((2 * D + 31) / 32);
+    int range = q->outputs_per_block;
+    if (range <= 0 || (range & 31)) return fail_inval("outputs_per_block must be a positive multiple of 32");
+    // every frame the kernel touches must lie inside [0, n_frames): columns b in [m_first-64, last], each read
+    // from frame b*D+1 for 16*ksteps frames (the k padding reads past the row into the next one)
+    const int64_t blocks = (n_out + range - 1) / range;
+    const int64_t last_cnt = n_out - (blocks - 1) * range;
+    const int64_t last_tiles = (last_cnt + 63 + 31) / 32;
+    const int64_t b_min = m_first - MF_Q;
+    const int64_t b_max = m_first + (blocks - 1) * range - MF_Q + last_tiles * 32 - 1;
+    const int64_t f_min = b_min * D + 1 - consumed;
+    const int64_t f_max = b_max * D + 1 - consumed + 16LL * ksteps - 1;
+    // full blocks are also bounded by their own tile count
+    const int64_t full_tiles = (static_cast<int64_t>(range) + 63 + 31) / 32;
+    const int64_t b_max_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q + full_tiles * 32 - 1 : b_max;
+    const int64_t f_max_full = b_max_full * D + 1 - consumed + 16LL * ksteps - 1;
+    if (f_min < 0 || f_max >= n_frames || f_max_full >= n_frames)
+        return fail_inval("MFMA channelizer range reads outside the block (use iqa_channelize for the edges)");
+    const int64_t acc_len = full_tiles * 32 + MF_Q + 4;
+    const size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int);
+    if (lds > 160 * 1024) return fail_inval("tap fragments + accumulators exceed 160 KiB of LDS");
+
+    MfmaArgs a;
+    a.afrag = static_cast<const v4i_t *>(afrag_dev);
+    a.raw = static_cast<const int *>(raw_dev);
+    a.out = static_cast<float2 *>(z_out_dev);
+    a.consumed = consumed;
+    a.m_lo = m_first;
+    a.n_out = n_out;
+    a.D = static_cast<int>(D);
+    a.ksteps = ksteps;
+    a.range = range;
+    a.unit = q->unit;
+    a.c_re = q->c_re;
+    a.c_im = q->c_im;
+    a.conj_sum = p->conj_sum;
+    a.rotate = p->rotate;
+    a.rot_step = p->rot_step;
+    a.rot_base = p->rot_base;
+    a.sc_re = p->out_scale_re;
+    a.sc_im = p->out_scale_im;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_channelize_mfma_s16, dim3(static_cast<unsigned>(blocks)), dim3(MF_THREADS), lds,
+                       as_stream(stream), a);
+    return check_launch("k_channelize_mfma_s16");
+}

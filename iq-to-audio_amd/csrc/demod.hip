@@ -349,22 +349,44 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
     pcm[i] = static_cast<short>(fmin(fmax(v, -32768.0), 32767.0));
 }
 
-// 48 kHz polyphase resampler: one thread per output, float64 accumulate.
-__global__ void k_resample(const float *x, long long n_in, const double *table, int up, int down, int T, long long j0,
-                           long long n_out, float *y)
+// 48 kHz polyphase resampler, float64 accumulate.  Row-stationary: outputs j and j+up use the
+// same polyphase row (phase p = (j*down) mod up), so one wave owns one row, keeps its 2T+1
+// taps in registers (lane t holds taps t and t+64) and walks j = j_first, j_first+up, ...;
+// per output it reads the 2T+1 input samples coalesced and does a 64-lane butterfly sum.
+// Table traffic drops from (2T+1)*8 B per output to one pass over the table.
+constexpr int RS_WAVES = 4;
+__global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
+                                                               int down, int T, long long j0, long long n_out, float *y)
 {
-    const long long jj = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long w = static_cast<long long>(blockIdx.x) * RS_WAVES + (threadIdx.x >> 6);  // wave id = residue of j+j0 mod up
+    if (w >= up) return;
+    const int row_len = 2 * T + 1;
+    // first output (relative index jj) with (j0 + jj) % up == w
+    long long jj = (w - (j0 % up) + up) % up;
     if (jj >= n_out) return;
-    const long long c = (j0 + jj) * down;
-    const long long q = c / up;
-    const int p = static_cast<int>(c - q * up);
-    const double *row = table + static_cast<long long>(p) * (2 * T + 1);
-    double acc = 0.0;
-    for (int t = 0; t <= 2 * T; ++t) {
-        const long long nidx = q - (t - T);
-        if (nidx >= 0 && nidx < n_in) acc = fma(row[t], static_cast<double>(x[nidx]), acc);
+    const long long c0 = (j0 + jj) * down;
+    const int p = static_cast<int>(c0 % up);
+    const double *row = table + static_cast<long long>(p) * row_len;
+    const double h0 = lane < row_len ? row[lane] : 0.0;
+    const double h1 = lane + 64 < row_len ? row[lane + 64] : 0.0;
+    const double h2 = lane + 128 < row_len ? row[lane + 128] : 0.0;  // rows up to 192 taps (T <= 95)
+    for (; jj < n_out; jj += up) {
+        const long long q = ((j0 + jj) * down) / up;
+        const long long nb = q + T - lane;  // input index for tap t = lane
+        double acc = 0.0;
+        if (lane < row_len && nb >= 0 && nb < n_in) acc = h0 * static_cast<double>(x[nb]);
+        if (row_len > 64) {
+            const long long n1 = nb - 64;
+            if (lane + 64 < row_len && n1 >= 0 && n1 < n_in) acc = fma(h1, static_cast<double>(x[n1]), acc);
+        }
+        if (row_len > 128) {
+            const long long n2 = nb - 128;
+            if (lane + 128 < row_len && n2 >= 0 && n2 < n_in) acc = fma(h2, static_cast<double>(x[n2]), acc);
+        }
+        const double tot = wave_sum(acc);
+        if (lane == 0) y[jj] = static_cast<float>(tot);
     }
-    y[jj] = static_cast<float>(acc);
 }
 
 template <int OP>
@@ -527,7 +549,8 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     if (n_in < 0 || n_out < 0 || j0 < 0 || up < 1 || down < 1 || T < 0) return fail_inval("bad resampler sizes");
     if (n_out == 0) return IQA_OK;
     if (!table_dev || !y_dev || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
-    hipLaunchKernelGGL(k_resample, grid1d(n_out, 256), dim3(256), 0, as_stream(stream),
+    if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
+    hipLaunchKernelGGL(k_resample, grid1d(up, RS_WAVES), dim3(RS_WAVES * kWave), 0, as_stream(stream),
                        static_cast<const float *>(x_dev), (long long)n_in, static_cast<const double *>(table_dev),
                        (int)up, (int)down, (int)T, (long long)j0, (long long)n_out, static_cast<float *>(y_dev));
     return check_launch("k_resample");

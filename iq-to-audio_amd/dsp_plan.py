@@ -110,6 +110,7 @@ class ChannelPlan:
     rot_step: int
     rot_base: int
     out_scale: complex
+    taps_natural: np.ndarray | None = None  # complex128 [L], natural order g[k] (same folding), for the MFMA planner
 
 
 def plan_channel(
@@ -155,8 +156,78 @@ def plan_channel(
     win[:ntaps] = g[::-1].astype(np.complex64)  # window order: win[i] multiplies x[n0-(L-1)+i]
     return ChannelPlan(
         fmt=fmt, ntaps=ntaps, decimation=int(decimation), taps_window=win, conj_sum=int(conj), rotate=1,
-        rot_step=(w * int(decimation)) % TWO64, rot_base=0, out_scale=c,
+        rot_step=(w * int(decimation)) % TWO64, rot_base=0, out_scale=c, taps_natural=g.astype(np.complex128),
     )
+
+
+MFMA_Q = 64  # q slots per output component in the int8-MFMA kernel
+
+
+@dataclass
+class MfmaPlan:
+    """Host-side operands of ``iqa_channelize_mfma`` (see csrc/channelize_mfma.hip)."""
+
+    ksteps: int
+    afrag: np.ndarray  # int8 [ksteps, 4, 2, 64, 16] tap fragments in MFMA lane order
+    unit: float  # value of one tap LSB
+    c_re: float  # 128 * sum(T) over the real-output rows
+    c_im: float
+    tq: np.ndarray  # int64 [128, Kpad] quantised taps T = 256*q1 + q2 (kept for tests)
+
+
+def mfma_supported(plan: ChannelPlan) -> bool:
+    return plan.fmt == "s16" and plan.taps_natural is not None and -(-plan.ntaps // plan.decimation) <= MFMA_Q
+
+
+def plan_mfma(plan: ChannelPlan) -> MfmaPlan:
+    """Quantise the (already NCO-rotated, scaled) taps to 16-bit fixed point and lay them out as
+    the A operand of v_mfma_i32_32x32x32_i8.
+
+    Rows: row = comp*64 + (q-1), q = 1..64; columns kap = 2*rho + c over one data row of D frames:
+        A[(re,q)][2rho] = Re g[qD-1-rho]   A[(re,q)][2rho+1] = -Im g[qD-1-rho]
+        A[(im,q)][2rho] = Im g[qD-1-rho]   A[(im,q)][2rho+1] =  Re g[qD-1-rho]
+    T = rint(A/u), u = max|A|/32639; T = 256*q1 + q2 with both bytes signed.
+    Fragment order (verified on hardware): lane l holds row l&31, k = 16*(l>>5) + j.
+    """
+    if not mfma_supported(plan):
+        raise ValueError("MFMA channelizer needs an int16 capture and ceil(ntaps/decimation) <= 64")
+    g = plan.taps_natural
+    L, D = plan.ntaps, plan.decimation
+    ksteps = -(-2 * D // 32)
+    kpad = 32 * ksteps
+    q = np.arange(1, MFMA_Q + 1, dtype=np.int64)[:, None]
+    rho = np.arange(D, dtype=np.int64)[None, :]
+    k = q * D - 1 - rho
+    ok = (k >= 0) & (k < L)
+    gk = np.where(ok, g[np.clip(k, 0, L - 1)], 0.0)
+    a = np.zeros((2 * MFMA_Q, kpad), dtype=np.float64)
+    a[:MFMA_Q, 0 : 2 * D : 2] = gk.real
+    a[:MFMA_Q, 1 : 2 * D : 2] = -gk.imag
+    a[MFMA_Q:, 0 : 2 * D : 2] = gk.imag
+    a[MFMA_Q:, 1 : 2 * D : 2] = gk.real
+    amax = float(np.max(np.abs(a)))
+    unit = amax / 32639.0 if amax > 0 else 1.0
+    t = np.rint(a / unit).astype(np.int64)
+    q2 = ((t + 128) & 255) - 128
+    q1 = (t - q2) >> 8
+    assert q1.min() >= -128 and q1.max() <= 127
+    pieces = np.stack([q1, q2]).astype(np.int8)  # [piece, row, kap]
+    lane = np.arange(64)
+    rows = (np.arange(4) * 32)[:, None] + (lane & 31)[None, :]  # [rt, lane]
+    cols = (32 * np.arange(ksteps))[:, None, None] + (16 * (lane >> 5))[None, :, None] + np.arange(16)[None, None, :]
+    # pieces[piece][rows[rt, lane], cols[ks, lane, j]] -> [piece, ks, rt, lane, j] -> [ks, rt, piece, lane, j]
+    frag = pieces[:, rows[None, :, :, None], cols[:, None, :, :]].transpose(1, 2, 0, 3, 4)
+    return MfmaPlan(ksteps, np.ascontiguousarray(frag), unit, 128.0 * float(t[:MFMA_Q].sum()),
+                    128.0 * float(t[MFMA_Q:].sum()), t)
+
+
+def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decimation: int, ksteps: int):
+    """(m_a, m_b): the sub-range of outputs [m_first, m_first+n_out) whose whole MFMA read range
+    (columns m-64 .. m+29, each 16*ksteps frames from frame b*D+1) lies inside this block's frames."""
+    d = decimation
+    m_a = max(m_first, MFMA_Q + -(-max(consumed - 1, 0) // d))
+    m_b = min(m_first + n_out, (n_frames + consumed - 16 * ksteps) // d - 30)
+    return (m_a, m_b) if m_b > m_a else (m_first, m_first)
 
 
 def plan_plain_fir(taps: np.ndarray, padded_len: int | None = None) -> ChannelPlan:

@@ -138,7 +138,17 @@ class ComplexOscillator:
 
 
 class _ChannelKernel:
-    """Shared launcher for the fused channelizer kernel (``iqa_channelize``)."""
+    """Shared launcher for the fused channelizer kernels.
+
+    ``iqa_channelize`` (float32 VALU form, every format, guarded edges) is always available;
+    for int16 captures with ceil(L/D) <= 64 the interior of each block runs on the int8-MFMA
+    form ``iqa_channelize_mfma`` and only the few outputs that touch the history (head) or the
+    end of the block (tail) go through the VALU kernel.
+    """
+
+    #: set to False to force the float32 VALU kernel everywhere (tests compare the two)
+    use_mfma = True
+    mfma_min_outputs = 32768
 
     def __init__(self, plan: P.ChannelPlan):
         self.plan = plan
@@ -151,12 +161,56 @@ class _ChannelKernel:
             rotate=plan.rotate, reserved=0, rot_step=plan.rot_step, rot_base=plan.rot_base,
             out_scale_re=float(np.real(plan.out_scale)), out_scale_im=float(np.imag(plan.out_scale)),
         )
+        self.mfma = None  # planned lazily, the first time a block is long enough to use it
+        self._mfma_range = 0
+        if self.use_mfma and P.mfma_supported(plan):
+            afrag_bytes = int(N.lib().iqa_mfma_afrag_bytes(plan.decimation))
+            budget = 80 * 1024 if afrag_bytes <= 56 * 1024 else 160 * 1024  # two blocks per CU when they fit
+            rng = ((budget - afrag_bytes) // 16 - 160) // 32 * 32
+            if rng >= 256:
+                self._mfma_range = min(rng, 2048)
 
-    def run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev=None):
+    def _ensure_mfma(self):
+        if self.mfma is None:
+            mp = P.plan_mfma(self.plan)
+            self.mfma = mp
+            self.afrag_dev = D.from_numpy(mp.afrag.reshape(-1).view(np.uint8))
+            self.mfma_params = N.MfmaParams(outputs_per_block=self._mfma_range, reserved=0, unit=mp.unit,
+                                            c_re=mp.c_re, c_im=mp.c_im)
+        return self.mfma
+
+    def _valu(self, raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev):
+        if n_out > 0:
+            N.call("iqa_channelize", byref(self.params), N.ptr(self.taps_dev), N.ptr(raw_dev), c_int64(n_frames),
+                   c_int64(consumed), N.ptr(hist_dev), c_int64(m_first), c_int64(n_out), N.ptr(out_dev), N.stream_ptr())
+
+    def run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev=None,
+            events=None):
+        """``events``: optional (start, stop) torch.cuda.Event pair recorded around the dominant launch."""
         if out_dev is None:
             out_dev = D.empty(n_out, "complex64")
-        N.call("iqa_channelize", byref(self.params), N.ptr(self.taps_dev), N.ptr(raw_dev), c_int64(n_frames),
-               c_int64(consumed), N.ptr(hist_dev), c_int64(m_first), c_int64(n_out), N.ptr(out_dev), N.stream_ptr())
+        self.last_kernel = "k_channelize_v1"
+        if self._mfma_range and n_out >= self.mfma_min_outputs:
+            ksteps = -(-2 * self.plan.decimation // 32)
+            m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, self.plan.decimation, ksteps)
+            if m_b - m_a >= self.mfma_min_outputs:
+                self._ensure_mfma()
+                self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
+                self.last_kernel = "k_channelize_mfma_s16"
+                if events:
+                    events[0].record()
+                N.call("iqa_channelize_mfma", byref(self.params), byref(self.mfma_params), N.ptr(self.afrag_dev),
+                       N.ptr(raw_dev), c_int64(n_frames), c_int64(consumed), c_int64(m_a), c_int64(m_b - m_a),
+                       N.ptr(out_dev[m_a - m_first :]), N.stream_ptr())
+                if events:
+                    events[1].record()
+                self._valu(raw_dev, n_frames, consumed, hist_dev, m_b, m_first + n_out - m_b, out_dev[m_b - m_first :])
+                return out_dev
+        if events:
+            events[0].record()
+        self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev)
+        if events:
+            events[1].record()
         return out_dev
 
 
@@ -257,14 +311,14 @@ class Channelizer:
         m_end = -(-(self.consumed + n_frames) // d)
         return m_first, m_end - m_first
 
-    def process(self, raw, out_dev=None):
+    def process(self, raw, out_dev=None, events=None):
         """``raw``: interleaved frames (NumPy or device tensor, dtype of ``fmt``; complex64 for f32).
         Returns the decimated complex64 samples for this block."""
         x, n = _as_frames(raw, self.fmt)
         if n == 0:
             return D.like_input(D.empty(0, "complex64"), raw)
         m_first, n_out = self.outputs_for(n)
-        z = self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev) if n_out else D.empty(0, "complex64")
+        z = self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events) if n_out else D.empty(0, "complex64")
         keep = self.ntaps - 1
         if keep:
             nxt = D.empty(keep * iqio.FRAME_BYTES[self.fmt], "uint8")

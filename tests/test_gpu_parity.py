@@ -471,3 +471,50 @@ def test_pipeline_cancel_removes_partial_output(A, tmp_path):
     with pytest.raises(A.ProcessingCancelled):
         pipe.run(Sink())
     assert not out.exists()
+
+
+# ---- int8-MFMA form of the channelizer -----------------------------------------------------------
+
+
+@pytest.mark.parametrize("fs,d,bw,n", [(2.5e6, 26, 12500.0, 4_000_000), (10e6, 104, 12500.0, 6_000_000)])
+def test_mfma_channelizer_vs_valu_and_oracle(A, fs, d, bw, n):
+    """The matrix-core path (exact int32 accumulation of int8 pieces, 16-bit fixed-point taps) against the
+    float32 VALU kernel and the oracle: error is the documented tap-quantisation floor (~2e-6 of full
+    scale), results are bit-reproducible, and head/tail outputs (history / end of block) are seamless."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import processing as PR
+
+    f_off = 25e3
+    raw = O.synth_capture_s16(fs, n / fs, f_off).reshape(-1)
+    taps = A.design_channel_filter(fs, bw, d)
+    x = D.to_device(raw, "int16")
+    old_min = PR._ChannelKernel.mfma_min_outputs
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 4096
+        outs = {}
+        for use in (False, True):
+            PR._ChannelKernel.use_mfma = use
+            ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
+            # two ragged blocks: the second one starts with a history and a non-zero decimator phase
+            cut = 2 * 1_500_001
+            z = torch.cat([ch.process(x[:cut]), ch.process(x[cut:])])
+            assert (ch._kernel.last_kernel == "k_channelize_mfma_s16") == use
+            outs[use] = z
+        PR._ChannelKernel.use_mfma = True
+        ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
+        again = torch.cat([ch.process(x[: 2 * 1_500_001]), ch.process(x[2 * 1_500_001 :])])
+        assert torch.equal(again, outs[True])  # integer accumulation: bit-reproducible
+    finally:
+        PR._ChannelKernel.use_mfma = True
+        PR._ChannelKernel.mfma_min_outputs = old_min
+    valu, mfma = outs[False].cpu().numpy(), outs[True].cpu().numpy()
+    assert valu.shape == mfma.shape == (-(-n // d),)
+    n_cpu = 1_000_000
+    want = O.decimate(O.overlap_save(O.nco_mix(O.ingest_to_complex64(raw[: 2 * n_cpu], "s16"), O.NcoState(f_off, fs), 1),
+                                     O.OverlapSaveState(taps, 65536)), O.DecimState(d))
+    k = want.size
+    assert rms(valu[:k] - want) < 2e-7
+    assert rms(mfma[:k] - want) < 4e-6 and np.abs(mfma[:k] - want).max() < 2e-5
+    assert rms(mfma - valu) < 4e-6 and np.abs(mfma - valu).max() < 2e-5
