@@ -183,6 +183,28 @@ int iqa_dc_block(const void *x_dev, int64_t n, double radius, void *state_dev, v
 int iqa_agc(const void *x_dev, int64_t n, double target, double decay, const void *reset_starts_dev,
             int64_t n_resets, void *y_dev, void *work_dev, void *stream);
 
+/*
+ * Whole demodulator + AudioWriter.write for a block of channel samples, in three launches.
+ * ref: decoder.process (processing.py:1128) for nfm / am / usb / lsb as listed above, followed by
+ *      AudioWriter.write (processing.py:1147 -> :440-456) and the per-chunk rms statistic.
+ * The source stage (discriminator / |z| / real) and the sink (pre-clip peak, clip +-0.99, per-segment
+ * sum of squares) are fused into the scan passes.  state_dev: 32 bytes {float2 prev (init 1+0j);
+ * double y_last; double x_last, y_last}, carried across calls.  seg_starts_dev: sorted int64 chunk
+ * starts within this block (seg_starts[0] == 0): AGC restarts + statistics segments.
+ * scratch_dev: float[n], only used by SSB with AGC.  work_dev: iqa_scan_workspace_bytes(n).
+ */
+typedef struct {
+    int32_t mode;        /* iqa_demod */
+    int32_t agc_enabled; /* honoured for USB/LSB only, as in the reference */
+    double deemph_alpha; /* exp(-1/(fs_ch*tau)) */
+    double dc_radius;    /* 0.995 */
+    double agc_target;   /* 10^(-12/20) */
+    double agc_decay;    /* 0.001 */
+} iqa_demod_params;
+int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
+                   const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev, void *audio_out_dev,
+                   void *scratch_dev, void *work_dev, void *stream);
+
 /* ref: AudioWriter.write, processing.py:440-456: peak = max(peak, max|a|) BEFORE the clip, then
  * clip to +-0.99.  peak_dev = float[1] (running, init 0).  In-place allowed (out_dev == a_dev).
  * Also accumulates sum(a^2) (pre-clip, float64) into sumsq_dev[seg] for the rms_dbfs statistic

@@ -46,6 +46,15 @@ class MfmaParams(ctypes.Structure):
                 ("c_im", c_double)]
 
 
+class DemodParams(ctypes.Structure):
+    """``iqa_demod_params`` (include/iqa_hotpath.h)."""
+
+    _fields_ = [("mode", c_int32), ("agc_enabled", c_int32), ("deemph_alpha", c_double), ("dc_radius", c_double),
+                ("agc_target", c_double), ("agc_decay", c_double)]
+
+
+DEMOD_MODE = {"nfm": 0, "fm": 0, "am": 1, "usb": 2, "ssb": 2, "lsb": 3}
+
 _SIGNATURES = {
     "iqa_abi_version": (ctypes.c_int, []),
     "iqa_last_error": (ctypes.c_char_p, []),
@@ -66,6 +75,8 @@ _SIGNATURES = {
     "iqa_deemphasis": (ctypes.c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iqa_dc_block": (ctypes.c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iqa_agc": (ctypes.c_int, [c_void_p, c_int64, c_double, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "iqa_demodulate": (ctypes.c_int, [ctypes.POINTER(DemodParams), c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iqa_writer_clip": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "iqa_resample": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64, c_void_p,
                                     c_void_p]),

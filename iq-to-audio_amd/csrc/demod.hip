@@ -15,21 +15,11 @@
 // associatively, so they run here as a 3-launch block scan (reduce -> carry -> apply)
 // in float64.  The AGC's "gain restarts at 1.0 on every process() call" becomes a
 // segmented scan: at a restart index the element's map is the constant a+b.
-#include "common.h"
+#include "scan_common.h"
 
 namespace iqa {
 
-constexpr int SC_THREADS = 256;
-constexpr int SC_ITEMS = 8;
-constexpr int SC_TILE = SC_THREADS * SC_ITEMS;  // 2048 elements per block
-
 enum ScanOp { OP_DEEMPH = 0, OP_DC = 1, OP_AGC = 2 };
-
-struct Aff {  // s -> A*s + B
-    double A, B;
-};
-// apply `l` first, then `r`
-__device__ __forceinline__ Aff then(const Aff &l, const Aff &r) { return Aff{r.A * l.A, fma(r.A, l.B, r.B)}; }
 
 struct ScanArgs {
     const float *x;
@@ -89,20 +79,6 @@ __device__ __forceinline__ Aff element_map(const ScanArgs &a, long long idx, flo
         if (maybe_reset && is_reset(a, idx)) m = Aff{0.0, m.A + m.B};  // gain restarts at 1.0
         return m;
     }
-}
-
-// ordered block-wide composition helpers --------------------------------------------------------
-
-// inclusive ordered wave scan; returns inclusive prefix for this lane
-__device__ __forceinline__ Aff wave_inclusive(Aff v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const double la = __shfl_up(v.A, o, kWave);
-        const double lb = __shfl_up(v.B, o, kWave);
-        if (lane >= o) v = then(Aff{la, lb}, v);
-    }
-    return v;
 }
 
 template <int OP>
@@ -350,42 +326,50 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 }
 
 // 48 kHz polyphase resampler, float64 accumulate.  Row-stationary: outputs j and j+up use the
-// same polyphase row (phase p = (j*down) mod up), so one wave owns one row, keeps its 2T+1
-// taps in registers (lane t holds taps t and t+64) and walks j = j_first, j_first+up, ...;
-// per output it reads the 2T+1 input samples coalesced and does a 64-lane butterfly sum.
-// Table traffic drops from (2T+1)*8 B per output to one pass over the table.
+// same polyphase row (phase p = (j*down) mod up).  A wave owns one row (or 1/split of its
+// outputs), keeps the row's taps in registers spread over 16 lanes (lane `sub` holds taps
+// sub, sub+16, ...), and computes FOUR outputs per pass, one per quarter-wave, so the
+// cross-lane reduction is 4 butterfly steps per 4 outputs.  Input windows are read as
+// contiguous 16-float runs; the table is read once in total.
 constexpr int RS_WAVES = 4;
+constexpr int RS_MAX_NI = 12;  // rows up to 192 taps
 __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
-                                                               int down, int T, long long j0, long long n_out, float *y)
+                                                               int down, int T, long long j0, long long n_out, float *y,
+                                                               int split)
 {
-    const int lane = threadIdx.x & 63;
-    const long long w = static_cast<long long>(blockIdx.x) * RS_WAVES + (threadIdx.x >> 6);  // wave id = residue of j+j0 mod up
+    const int lane = threadIdx.x & 63, sub = lane & 15, quarter = lane >> 4;
+    const long long wid = static_cast<long long>(blockIdx.x) * RS_WAVES + (threadIdx.x >> 6);
+    const long long w = wid / split;  // residue of (j0 + jj) mod up handled by this wave
+    const int part = static_cast<int>(wid - w * split);
     if (w >= up) return;
     const int row_len = 2 * T + 1;
-    // first output (relative index jj) with (j0 + jj) % up == w
-    long long jj = (w - (j0 % up) + up) % up;
-    if (jj >= n_out) return;
-    const long long c0 = (j0 + jj) * down;
-    const int p = static_cast<int>(c0 % up);
+    const int ni = (row_len + 15) >> 4;
+    const long long jj0 = (w - (j0 % up) + up) % up;  // first output of this row
+    if (jj0 >= n_out) return;
+    const long long g_total = (n_out - jj0 + up - 1) / up;
+    const long long g_per = ((g_total + split - 1) / split + 3) & ~3LL;
+    const long long g_lo = part * g_per, g_hi = min(g_total, g_lo + g_per);
+    if (g_lo >= g_hi) return;
+    const int p = static_cast<int>(((j0 + jj0) * down) % up);
     const double *row = table + static_cast<long long>(p) * row_len;
-    const double h0 = lane < row_len ? row[lane] : 0.0;
-    const double h1 = lane + 64 < row_len ? row[lane + 64] : 0.0;
-    const double h2 = lane + 128 < row_len ? row[lane + 128] : 0.0;  // rows up to 192 taps (T <= 95)
-    for (; jj < n_out; jj += up) {
+    double h[RS_MAX_NI];
+#pragma unroll
+    for (int i = 0; i < RS_MAX_NI; ++i) h[i] = (i < ni && sub + 16 * i < row_len) ? row[sub + 16 * i] : 0.0;
+    for (long long g = g_lo + quarter; g < g_hi + quarter; g += 4) {  // all quarters iterate together
+        const bool live = g < g_hi;
+        const long long jj = jj0 + g * up;
         const long long q = ((j0 + jj) * down) / up;
-        const long long nb = q + T - lane;  // input index for tap t = lane
         double acc = 0.0;
-        if (lane < row_len && nb >= 0 && nb < n_in) acc = h0 * static_cast<double>(x[nb]);
-        if (row_len > 64) {
-            const long long n1 = nb - 64;
-            if (lane + 64 < row_len && n1 >= 0 && n1 < n_in) acc = fma(h1, static_cast<double>(x[n1]), acc);
+#pragma unroll
+        for (int i = 0; i < RS_MAX_NI; ++i) {
+            if (i < ni) {
+                const long long nidx = q + T - (sub + 16 * i);
+                if (live && nidx >= 0 && nidx < n_in) acc = fma(h[i], static_cast<double>(x[nidx]), acc);
+            }
         }
-        if (row_len > 128) {
-            const long long n2 = nb - 128;
-            if (lane + 128 < row_len && n2 >= 0 && n2 < n_in) acc = fma(h2, static_cast<double>(x[n2]), acc);
-        }
-        const double tot = wave_sum(acc);
-        if (lane == 0) y[jj] = static_cast<float>(tot);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);  // stays inside the 16-lane group
+        if (live && sub == 0) y[jj] = static_cast<float>(acc);
     }
 }
 
@@ -550,9 +534,12 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     if (n_out == 0) return IQA_OK;
     if (!table_dev || !y_dev || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
     if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
-    hipLaunchKernelGGL(k_resample, grid1d(up, RS_WAVES), dim3(RS_WAVES * kWave), 0, as_stream(stream),
-                       static_cast<const float *>(x_dev), (long long)n_in, static_cast<const double *>(table_dev),
-                       (int)up, (int)down, (int)T, (long long)j0, (long long)n_out, static_cast<float *>(y_dev));
+    const int64_t g_total = (n_out + up - 1) / up;  // outputs per polyphase row
+    const int split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(16, (g_total + 31) / 32)));
+    hipLaunchKernelGGL(k_resample, grid1d(static_cast<int64_t>(up) * split, RS_WAVES), dim3(RS_WAVES * kWave), 0,
+                       as_stream(stream), static_cast<const float *>(x_dev), (long long)n_in,
+                       static_cast<const double *>(table_dev), (int)up, (int)down, (int)T, (long long)j0, (long long)n_out,
+                       static_cast<float *>(y_dev), split);
     return check_launch("k_resample");
 }
 

@@ -1,0 +1,336 @@
+// demod_fused.hip -- whole demodulator + AudioWriter.write for a block of channel samples in three
+// launches (reduce -> carry -> apply), instead of one launch per reference stage.
+//
+// Replaces, for one block of decimated samples z (reference src/iq_to_audio/):
+//   decoder.process(z)            processing.py:1128
+//     nfm: QuadratureDemod + DeemphasisFilter      decoders/nfm.py:17-24, 48-62
+//     am : abs + DCBlocker                         decoders/am.py:28, decoders/common.py:16-30
+//     ssb: real + DCBlocker [+ _apply_agc]         decoders/ssb.py:42-45, 65-80
+//   audio_writer.write(audio)     processing.py:1147 -> :440-456 (pre-clip peak, clip +-0.99)
+//   stats rms_dbfs per chunk      decoders/nfm.py:88-89 (sum of squares per reference chunk)
+//
+// The source stage (discriminator / envelope / real part) is evaluated on the fly inside the
+// scan passes, and the sink (peak, clip, per-chunk sum of squares) inside the apply pass, so z is
+// read twice and the audio written once: 20 B per channel sample instead of ~52.
+// SSB with AGC needs two dependent recurrences and therefore two scans (DC blocker to a float
+// scratch, then the segmented AGC scan with the sink).
+#include "scan_common.h"
+
+namespace iqa {
+
+enum FOp { F_DEEMPH = 0, F_DC = 1, F_AGC = 2 };
+enum FSrc { S_F32 = 0, S_QUAD = 1, S_ENV = 2, S_REAL = 3 };
+enum FSink { K_PLAIN = 0, K_CLIP = 1 };
+
+struct FusedArgs {
+    const float2 *z;     // S_QUAD / S_ENV / S_REAL
+    const float *x;      // S_F32
+    float *y;
+    long long n;
+    double p0, p1;       // DEEMPH: alpha, 1-alpha | DC: radius (f32-rounded) | AGC: target (f32), decay (f32)
+    const float2 *prev;  // S_QUAD: previous complex sample
+    const double *st;    // DEEMPH: {y_last} | DC: {x_last, y_last}
+    const long long *segs;  // chunk starts (AGC restarts and statistics segments), segs[0] == 0
+    long long n_segs;
+    unsigned int *peak_bits;
+    double *sumsq;
+    Aff *agg;
+    double *carry;
+    double *fin;
+    int nblocks;
+};
+
+template <int SRC>
+__device__ __forceinline__ float src_value(const FusedArgs &a, long long i, float2 zc, float2 zp)
+{
+    if constexpr (SRC == S_QUAD) {
+        const float re = zc.x * zp.x + zc.y * zp.y;  // z * conj(z_prev), float32 as numpy forms it
+        const float im = zc.y * zp.x - zc.x * zp.y;
+        return atan2f(im, re);
+    } else if constexpr (SRC == S_ENV) {
+        return hypotf(zc.x, zc.y);
+    } else {
+        return zc.x;
+    }
+}
+
+// u[base-1 .. base+7] -> x[0..7] plus x_before (only DC needs u[base-1])
+template <int OP, int SRC>
+__device__ __forceinline__ void load_u(const FusedArgs &a, long long base, float (&u)[SC_ITEMS], float &u_before)
+{
+    u_before = 0.f;
+    if constexpr (SRC == S_F32) {
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i) u[i] = (base + i < a.n) ? a.x[base + i] : 0.f;
+        if constexpr (OP == F_DC) {
+            if (base == 0) u_before = static_cast<float>(a.st[0]);
+            else if (base - 1 < a.n) u_before = a.x[base - 1];
+        }
+    } else {
+        float2 zz[SC_ITEMS + 2];  // z[base-2 .. base+7]
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS + 2; ++i) {
+            const long long k = base - 2 + i;
+            zz[i] = (k >= 0 && k < a.n) ? a.z[k] : make_float2(0.f, 0.f);
+        }
+        if constexpr (SRC == S_QUAD) {
+            if (base == 0) zz[1] = a.prev[0];  // z[-1]
+        }
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i) u[i] = (base + i < a.n) ? src_value<SRC>(a, base + i, zz[i + 2], zz[i + 1]) : 0.f;
+        if constexpr (OP == F_DC) {
+            // DC blocker's x[n-1]: u[base-1] from z (ENV/REAL never need z[base-2]); carried state at 0
+            if (base == 0) u_before = static_cast<float>(a.st[0]);
+            else u_before = src_value<SRC>(a, base - 1, zz[1], zz[0]);
+        }
+    }
+}
+
+template <int OP>
+__device__ __forceinline__ Aff fmap(const FusedArgs &a, long long idx, float x, float x_prev, bool maybe_reset)
+{
+    if constexpr (OP == F_DEEMPH) {
+        return Aff{a.p0, a.p1 * static_cast<double>(x)};
+    } else if constexpr (OP == F_DC) {
+        return Aff{a.p0, static_cast<double>(x - x_prev)};
+    } else {
+        const float mag = fabsf(x);
+        Aff m{1.0, 0.0};
+        if (mag > 1e-6f) {
+            const float desired = static_cast<float>(a.p0) / mag;
+            m = Aff{1.0 - a.p1, a.p1 * static_cast<double>(desired)};
+        }
+        if (maybe_reset) {
+            bool rst = (idx == 0);
+            if (!rst && a.segs != nullptr && a.n_segs > 0) {
+                const long long lo = lower_bound_ll(a.segs, a.n_segs, idx);
+                rst = lo < a.n_segs && a.segs[lo] == idx;
+            }
+            if (rst) m = Aff{0.0, m.A + m.B};
+        }
+        return m;
+    }
+}
+
+__device__ __forceinline__ bool block_has_restart(const FusedArgs &a, long long lo_i, long long hi_i)
+{
+    if (lo_i == 0) return true;
+    if (a.segs == nullptr || a.n_segs <= 0) return false;
+    const long long lo = lower_bound_ll(a.segs, a.n_segs, lo_i);
+    return lo < a.n_segs && a.segs[lo] < hi_i;
+}
+
+template <int OP, int SRC>
+__global__ __launch_bounds__(SC_THREADS) void k_fused_reduce(FusedArgs a)
+{
+    __shared__ Aff s_w[SC_THREADS / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long blk0 = static_cast<long long>(blockIdx.x) * SC_TILE;
+    const long long base = blk0 + static_cast<long long>(tid) * SC_ITEMS;
+    const bool mr = (OP == F_AGC) && block_has_restart(a, blk0, blk0 + SC_TILE);
+    float u[SC_ITEMS], ub;
+    load_u<OP, SRC>(a, base, u, ub);
+    Aff t{1.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i)
+        if (base + i < a.n) t = then(t, fmap<OP>(a, base + i, u[i], i ? u[i - 1] : ub, mr));
+    const Aff inc = wave_inclusive(t, lane);
+    if (lane == kWave - 1) s_w[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        Aff tot = s_w[0];
+#pragma unroll
+        for (int w = 1; w < SC_THREADS / kWave; ++w) tot = then(tot, s_w[w]);
+        a.agg[blockIdx.x] = tot;
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(kWave) void k_fused_carry(FusedArgs a)
+{
+    const int lane = threadIdx.x;
+    double s;
+    if constexpr (OP == F_DEEMPH) s = a.st[0];
+    else if constexpr (OP == F_DC) s = a.st[1];
+    else s = 1.0;
+    for (int c = 0; c < a.nblocks; c += kWave) {
+        const int b = c + lane;
+        const Aff v = (b < a.nblocks) ? a.agg[b] : Aff{1.0, 0.0};
+        const Aff inc = wave_inclusive(v, lane);
+        const double after = fma(inc.A, s, inc.B);
+        double before = __shfl_up(after, 1, kWave);
+        if (lane == 0) before = s;
+        if (b < a.nblocks) a.carry[b] = before;
+        s = __shfl(after, kWave - 1, kWave);
+    }
+    if (lane == 0) a.fin[0] = s;
+}
+
+template <int OP, int SRC, int SINK>
+__global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
+{
+    __shared__ Aff s_w[SC_THREADS / kWave];
+    __shared__ float s_pk[SC_THREADS / kWave];
+    __shared__ double s_sq[SC_THREADS / kWave];
+    __shared__ long long s_seg[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long blk0 = static_cast<long long>(blockIdx.x) * SC_TILE;
+    const long long base = blk0 + static_cast<long long>(tid) * SC_ITEMS;
+    const bool mr = (OP == F_AGC) && block_has_restart(a, blk0, blk0 + SC_TILE);
+    const bool stats = (SINK == K_CLIP) && a.sumsq != nullptr && a.n_segs > 0;
+    if (stats && tid < 2) {
+        const long long idx = tid == 0 ? blk0 : min(blk0 + SC_TILE, a.n) - 1;
+        s_seg[tid] = lower_bound_ll(a.segs, a.n_segs, idx + 1) - 1;  // last start <= idx
+    }
+    float u[SC_ITEMS], ub;
+    load_u<OP, SRC>(a, base, u, ub);
+    Aff m[SC_ITEMS];
+    Aff t{1.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        m[i] = (base + i < a.n) ? fmap<OP>(a, base + i, u[i], i ? u[i - 1] : ub, mr) : Aff{1.0, 0.0};
+        t = then(t, m[i]);
+    }
+    const Aff inc = wave_inclusive(t, lane);
+    if (lane == kWave - 1) s_w[wave] = inc;
+    __syncthreads();
+    const double ea = __shfl_up(inc.A, 1, kWave), eb = __shfl_up(inc.B, 1, kWave);
+    Aff ex = (lane == 0) ? Aff{1.0, 0.0} : Aff{ea, eb};
+    Aff wpre{1.0, 0.0};
+    for (int w = 0; w < wave; ++w) wpre = then(wpre, s_w[w]);
+    ex = then(wpre, ex);
+    double s = fma(ex.A, a.carry[blockIdx.x], ex.B);
+
+    const bool uniform = stats && (s_seg[0] == s_seg[1]);
+    long long seg = stats ? s_seg[0] : -1;
+    if (stats && !uniform && base < a.n) seg = lower_bound_ll(a.segs, a.n_segs, base + 1) - 1;
+    float pk = 0.f;
+    double run = 0.0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        s = fma(m[i].A, s, m[i].B);
+        const long long idx = base + i;
+        if (idx < a.n) {
+            const float v = (OP == F_AGC) ? u[i] * static_cast<float>(s) : static_cast<float>(s);
+            if constexpr (SINK == K_CLIP) {
+                pk = fmaxf(pk, fabsf(v));
+                a.y[idx] = fminf(fmaxf(v, -0.99f), 0.99f);
+                if (stats) {
+                    if (!uniform) {
+                        while (seg + 1 < a.n_segs && a.segs[seg + 1] <= idx) {
+                            if (run != 0.0) atomicAdd(&a.sumsq[seg], run);
+                            run = 0.0;
+                            ++seg;
+                        }
+                    }
+                    run += static_cast<double>(v) * static_cast<double>(v);
+                }
+            } else {
+                a.y[idx] = v;
+            }
+        }
+    }
+    if constexpr (SINK == K_CLIP) {
+        if (stats && !uniform && run != 0.0) atomicAdd(&a.sumsq[seg], run);
+        pk = wave_max(pk);
+        const double wsq = uniform ? wave_sum(run) : 0.0;
+        if (lane == 0) {
+            s_pk[wave] = pk;
+            s_sq[wave] = wsq;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.peak_bits != nullptr)
+                atomicMax(a.peak_bits, __float_as_uint(fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3]))));
+            if (uniform) atomicAdd(&a.sumsq[s_seg[0]], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
+        }
+    }
+}
+
+// after apply: hand the streaming state to the next block
+template <int OP, int SRC>
+__global__ void k_fused_finish(FusedArgs a, float2 *prev_out, double *st_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if constexpr (SRC == S_QUAD) prev_out[0] = a.z[a.n - 1];
+    if constexpr (OP == F_DEEMPH) {
+        st_out[0] = a.fin[0];
+    } else if constexpr (OP == F_DC) {
+        float last;
+        if constexpr (SRC == S_F32) last = a.x[a.n - 1];
+        else last = src_value<SRC>(a, a.n - 1, a.z[a.n - 1], make_float2(0.f, 0.f));
+        st_out[0] = static_cast<double>(last);
+        st_out[1] = a.fin[0];
+    }
+}
+
+template <int OP, int SRC, int SINK>
+static int launch_fused(FusedArgs a, float2 *prev_out, double *st_out, void *work, hipStream_t s)
+{
+    a.nblocks = static_cast<int>((a.n + SC_TILE - 1) / SC_TILE);
+    char *w = static_cast<char *>(work);
+    a.agg = reinterpret_cast<Aff *>(w);
+    a.carry = reinterpret_cast<double *>(w + sizeof(Aff) * a.nblocks);
+    a.fin = a.carry + a.nblocks;
+    hipLaunchKernelGGL((k_fused_reduce<OP, SRC>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, a);
+    hipLaunchKernelGGL((k_fused_carry<OP>), dim3(1), dim3(kWave), 0, s, a);
+    hipLaunchKernelGGL((k_fused_apply<OP, SRC, SINK>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, a);
+    if (OP != F_AGC) hipLaunchKernelGGL((k_fused_finish<OP, SRC>), dim3(1), dim3(1), 0, s, a, prev_out, st_out);
+    return check_launch("fused demodulator");
+}
+
+}  // namespace iqa
+
+using namespace iqa;
+
+extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
+                              const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev,
+                              void *audio_out_dev, void *scratch_dev, void *work_dev, void *stream)
+{
+    if (p == nullptr) return fail_inval("params is NULL");
+    if (n < 0 || n_segs < 0) return fail_inval("negative length");
+    if (p->mode < IQA_DEMOD_NFM || p->mode > IQA_DEMOD_LSB) return fail_inval("Unsupported demod mode");
+    if (n == 0) return IQA_OK;
+    if (!z_dev || !state_dev || !audio_out_dev || !work_dev) return fail_inval("NULL device pointer");
+    if (n_segs > 0 && !seg_starts_dev) return fail_inval("seg_starts is NULL");
+    hipStream_t s = as_stream(stream);
+    // state block: [0] float2 prev (8 B) | [8] double y_last | [16] double x_last, y_last
+    char *st = static_cast<char *>(state_dev);
+    FusedArgs a{};
+    a.z = static_cast<const float2 *>(z_dev);
+    a.n = n;
+    a.segs = static_cast<const long long *>(seg_starts_dev);
+    a.n_segs = n_segs;
+    a.peak_bits = static_cast<unsigned int *>(peak_dev);
+    a.sumsq = static_cast<double *>(sumsq_dev);
+    a.y = static_cast<float *>(audio_out_dev);
+    a.prev = reinterpret_cast<const float2 *>(st);
+    if (p->mode == IQA_DEMOD_NFM) {
+        a.p0 = p->deemph_alpha;
+        a.p1 = 1.0 - p->deemph_alpha;
+        a.st = reinterpret_cast<const double *>(st + 8);
+        return launch_fused<F_DEEMPH, S_QUAD, K_CLIP>(a, reinterpret_cast<float2 *>(st), reinterpret_cast<double *>(st + 8),
+                                                      work_dev, s);
+    }
+    if (!(p->dc_radius > 0.0 && p->dc_radius < 1.0)) return fail_inval("radius must be between 0 and 1");
+    a.p0 = static_cast<double>(static_cast<float>(p->dc_radius));
+    a.st = reinterpret_cast<const double *>(st + 16);
+    double *dc_out = reinterpret_cast<double *>(st + 16);
+    if (p->mode == IQA_DEMOD_AM) return launch_fused<F_DC, S_ENV, K_CLIP>(a, nullptr, dc_out, work_dev, s);
+    if (!p->agc_enabled) return launch_fused<F_DC, S_REAL, K_CLIP>(a, nullptr, dc_out, work_dev, s);
+    // SSB with AGC: DC blocker into scratch, then the segmented AGC scan with the writer sink
+    if (!scratch_dev) return fail_inval("SSB with AGC needs a float scratch buffer of n elements");
+    FusedArgs d = a;
+    d.y = static_cast<float *>(scratch_dev);
+    d.peak_bits = nullptr;
+    d.sumsq = nullptr;
+    int rc = launch_fused<F_DC, S_REAL, K_PLAIN>(d, nullptr, dc_out, work_dev, s);
+    if (rc != IQA_OK) return rc;
+    FusedArgs g = a;
+    g.z = nullptr;
+    g.x = static_cast<const float *>(scratch_dev);
+    g.p0 = static_cast<double>(static_cast<float>(p->agc_target));
+    g.p1 = static_cast<double>(static_cast<float>(p->agc_decay));
+    g.st = nullptr;
+    return launch_fused<F_AGC, S_F32, K_CLIP>(g, nullptr, nullptr, work_dev, s);
+}

@@ -395,19 +395,35 @@ class ProcessingCancelled(RuntimeError):  # noqa: N818
 
 
 class ChannelDemod:
-    """Demodulate many reference chunks in one call while keeping per-chunk semantics.
+    """Demodulate + AudioWriter.write for many reference chunks in one fused call.
 
-    Wraps a decoder from :func:`create_decoder`; the only per-chunk behaviour of the
-    reference decoders is the SSB AGC restart (decoders/ssb.py:72), expressed as restart
-    indices of the segmented scan.  Also applies AudioWriter's peak/clip
-    (processing.py:440-456) and collects per-chunk sum-of-squares for the rms_dbfs log.
+    ``decoder.process`` (processing.py:1128) followed by ``audio_writer.write`` (:1147) for a whole
+    block: the only per-chunk behaviour of the reference decoders is the SSB AGC restart
+    (decoders/ssb.py:72), expressed as restart indices of the segmented scan; the writer's pre-clip
+    peak, +-0.99 clip and the per-chunk sum of squares (rms_dbfs) are fused into the last scan pass
+    (``iqa_demodulate``).  ``self.decoder`` is the matching pluggable decoder object (kept for its
+    parameters and API parity; the fused path carries its own device state).
     """
 
     def __init__(self, mode: str, fs_channel: float, *, deemph_us: float, agc_enabled: bool):
         self.decoder = create_decoder(mode, deemph_us=deemph_us, agc_enabled=agc_enabled)
         self.decoder.setup(fs_channel)
+        from .decoders.nfm import NarrowbandFMDecoder
+        from .decoders.ssb import SSBDecoder
+
+        d = self.decoder
+        alpha = d._deemph.alpha if isinstance(d, NarrowbandFMDecoder) else 0.0
+        is_ssb = isinstance(d, SSBDecoder)
+        self.params = N.DemodParams(
+            mode=N.DEMOD_MODE[mode.lower()], agc_enabled=int(bool(agc_enabled)), deemph_alpha=alpha,
+            dc_radius=0.995 if isinstance(d, NarrowbandFMDecoder) else d._dc_blocker.radius,
+            agc_target=d._agc_level if is_ssb else 0.0, agc_decay=d._agc_decay if is_ssb else 0.0)
+        self._needs_scratch = is_ssb and bool(agc_enabled)
+        state = np.zeros(8, dtype=np.float32)  # {float2 prev = 1+0j; double y_last; double x_last, y_last}
+        state[0] = 1.0
+        self.state_dev = D.from_numpy(state)
         self.peak_dev = D.zeros(1, "float32")
-        self.chunk_sumsq: list = []  # (device float64[n_chunks], counts list)
+        self.chunk_sumsq: list = []  # (device float64[n_chunks], counts)
 
     def process(self, z_dev, chunk_starts: np.ndarray, out_dev):
         """z_dev -> clipped float32 audio written into ``out_dev`` (len == len(z_dev))."""
@@ -415,34 +431,14 @@ class ChannelDemod:
         if n == 0:
             return
         starts_dev = D.from_numpy(np.ascontiguousarray(chunk_starts, dtype=np.int64))
-        from .decoders.ssb import SSBDecoder
-
-        if isinstance(self.decoder, SSBDecoder):
-            audio = self._process_ssb(z_dev, starts_dev)
-        else:
-            audio = self._process_plain(z_dev)
         sumsq = D.zeros(len(chunk_starts), "float64")
-        N.call("iqa_writer_clip", N.ptr(audio), c_int64(n), N.ptr(self.peak_dev), N.ptr(starts_dev),
-               c_int64(len(chunk_starts)), N.ptr(sumsq), N.ptr(out_dev), N.stream_ptr())
+        work = D.empty(int(N.lib().iqa_scan_workspace_bytes(n)), "uint8")
+        scratch = D.empty(n, "float32") if self._needs_scratch else None
+        N.call("iqa_demodulate", byref(self.params), N.ptr(z_dev), c_int64(n), N.ptr(self.state_dev), N.ptr(starts_dev),
+               c_int64(len(chunk_starts)), N.ptr(self.peak_dev), N.ptr(sumsq), N.ptr(out_dev), N.ptr(scratch), N.ptr(work),
+               N.stream_ptr())
         counts = np.diff(np.append(chunk_starts, n))
         self.chunk_sumsq.append((sumsq, counts))
-
-    def _process_plain(self, z_dev):
-        d = self.decoder
-        from .decoders.nfm import NarrowbandFMDecoder
-
-        if isinstance(d, NarrowbandFMDecoder):
-            return d._deemph.process(d._demod.process(z_dev))
-        env = D.empty(z_dev.numel(), "float32")
-        N.call("iqa_envelope", N.ptr(z_dev), c_int64(z_dev.numel()), N.ptr(env), N.stream_ptr())
-        return d._dc_blocker.process(env)
-
-    def _process_ssb(self, z_dev, starts_dev):
-        d = self.decoder
-        base = D.empty(z_dev.numel(), "float32")
-        N.call("iqa_real_part", N.ptr(z_dev), c_int64(z_dev.numel()), N.ptr(base), N.stream_ptr())
-        dc = d._dc_blocker.process(base)
-        return d._apply_agc(dc, starts_dev) if d._agc_enabled else dc
 
     @property
     def peak(self) -> float:
