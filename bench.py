@@ -38,8 +38,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--seconds", type=float, default=60.0, help="capture length (config 2: 60 s)")
     ap.add_argument("--sample-rate", type=float, default=10e6)
     ap.add_argument("--unique-seconds", type=float, default=5.0, help="seed-42 prefix generated on the host, then tiled")
@@ -57,7 +57,7 @@ def main() -> None:
     from iq_to_audio_amd import _dev as D
     from iq_to_audio_amd import dsp_plan as P
     from iq_to_audio_amd.benchmark import synthetic_iq_s16
-    from iq_to_audio_amd.processing import ChannelDemod, Resampler48k
+    from iq_to_audio_amd.processing import ChannelDemod, MixSignProbe, Resampler48k
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,11 +101,19 @@ def main() -> None:
     kernel_name = ["?"]
 
     def step(i: int):
-        sign = A.choose_mix_sign(raw[: 2 * min(chunk, n_total)], fs, f_off, taps, d, fmt="s16")
-        chan = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=sign, decimation=d, fmt="s16")
+        # the two mixer-sign probes run on the GPU while the host plans the channelizer for the likely
+        # sign (+1) and stages the demodulator's small buffers; the read-back of the probe is the only
+        # host<->device synchronisation of a step
+        probe = MixSignProbe(raw[: 2 * min(chunk, n_total)], fs, f_off, taps, d, fmt="s16")
+        chan = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt="s16")
+        chan.plan_ahead()
+        dem = ChannelDemod("nfm", fs_ch, deemph_us=300.0, agc_enabled=True)
+        dem.prepare(n_dec, starts)
+        sign = probe.result()
+        if sign != 1:
+            chan = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=sign, decimation=d, fmt="s16")
         chan.process(raw, out_dev=z, events=(ev_k0[i], ev_k1[i]))
         kernel_name[0] = chan._kernel.last_kernel
-        dem = ChannelDemod("nfm", fs_ch, deemph_us=300.0, agc_enabled=True)
         dem.process(z, starts, audio)
         y48 = rs.process(audio)
         pcm = rs.to_pcm16(y48)
@@ -123,9 +131,14 @@ def main() -> None:
         step(i)
     fence()
     t0 = time.perf_counter()
+    marks = []
     for i in range(args.steps):
         sign, dem, y48 = step(args.warmup + i)
+        marks.append(time.perf_counter() - t0)
     fence()
+    if os.environ.get("IQA_BENCH_DEBUG"):
+        print("host-side step completion times (ms):", [round(m * 1e3, 2) for m in marks],
+              "after fence:", round((time.perf_counter() - t0) * 1e3, 2), file=sys.stderr)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=D.device())

@@ -32,6 +32,10 @@ extern "C" {
 #endif
 
 #define IQA_ABI_VERSION 1
+/* Per-segment sums of squares are spread over this many sub-slots (sumsq_dev holds n_segs*IQA_SUMSQ_SLOTS
+ * doubles, the caller adds the slots of a segment): float atomics on one address serialise at memory
+ * latency, so 40 blocks adding into one word cost ~65 us; eight words cost ~8 us. */
+#define IQA_SUMSQ_SLOTS 8
 
 typedef enum {
     IQA_OK = 0,
@@ -207,7 +211,7 @@ int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void
 
 /* ref: AudioWriter.write, processing.py:440-456: peak = max(peak, max|a|) BEFORE the clip, then
  * clip to +-0.99.  peak_dev = float[1] (running, init 0).  In-place allowed (out_dev == a_dev).
- * Also accumulates sum(a^2) (pre-clip, float64) into sumsq_dev[seg] for the rms_dbfs statistic
+ * Also accumulates sum(a^2) (pre-clip, float64) into sumsq_dev[seg*IQA_SUMSQ_SLOTS + slot] for the rms_dbfs statistic
  * (ref: decoders/nfm.py:88-89), where seg = index into seg_starts_dev (sorted int64[n_segs],
  * seg_starts[0] == 0); pass NULL/0 to skip.  peak_dev and out_dev may each be NULL (statistics only). */
 int iqa_writer_clip(const void *a_dev, int64_t n, void *peak_dev, const void *seg_starts_dev, int64_t n_segs,

@@ -110,10 +110,17 @@ __device__ __forceinline__ float2 load_guarded(const ChanArgs &a, long long f)
     return make_float2(0.f, 0.f);
 }
 
-template <int FMT>
+// SPLITK = false: throughput form (wave = 4 outputs x all taps; 32 outputs per block).
+// SPLITK = true : latency form for short launches (mixer-sign probe, head/tail of a block): the 8 waves
+//                 of a block share 4 outputs and split the taps 8 ways, so a 4800-output probe becomes
+//                 1200 blocks of 3-4 iterations instead of 151 blocks of 26.
+template <int FMT, bool SPLITK>
 __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
 {
     __shared__ __attribute__((aligned(16))) float2 s_taps[CH_TCH];
+    __shared__ float s_part[CH_WAVES][CH_R][2];
+    constexpr int OUT_PER_BLOCK = SPLITK ? CH_R : CH_OUT_PER_BLOCK;
+    constexpr int LANE_STRIDE = SPLITK ? CH_WAVES * kWave * 4 : kWave * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -125,8 +132,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
     const unsigned nblk = gridDim.x, per = nblk >> 3;
     unsigned tile = blockIdx.x;
     if (tile < per * 8u) tile = (tile & 7u) * per + (tile >> 3);
-    const long long o_blk = static_cast<long long>(tile) * CH_OUT_PER_BLOCK;
-    const long long o0 = o_blk + wave * CH_R;
+    const long long o_blk = static_cast<long long>(tile) * OUT_PER_BLOCK;
+    const long long o0 = o_blk + (SPLITK ? 0 : wave * CH_R);
+    const int lane0 = (SPLITK ? (wave * kWave + lane) : lane) * 4;
 
     // window start (local frame index) of each of this wave's outputs
     long long start[CH_R];
@@ -135,8 +143,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
 
     // block-uniform: can every lane of every wave read 4 frames unguarded?
     const long long blk_first = (a.m_first + o_blk) * a.D - a.consumed - (a.L - 1);
-    const long long blk_last = blk_first + static_cast<long long>(CH_OUT_PER_BLOCK - 1) * a.D;
-    const bool interior = (blk_first >= 0) && (blk_last + a.Lpad <= a.n_frames) && (o_blk + CH_OUT_PER_BLOCK <= a.n_out);
+    const long long blk_last = blk_first + static_cast<long long>(OUT_PER_BLOCK - 1) * a.D;
+    const bool interior = (blk_first >= 0) && (blk_last + a.Lpad <= a.n_frames) && (o_blk + OUT_PER_BLOCK <= a.n_out);
 
     float acc_re[CH_R], acc_im[CH_R];
 #pragma unroll
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
         __syncthreads();
 
         if (interior) {
-            for (int it = lane * 4; it < cnt; it += kWave * 4) {
+            for (int it = lane0; it < cnt; it += LANE_STRIDE) {
                 const float4 g01 = *reinterpret_cast<const float4 *>(&s_taps[it]);
                 const float4 g23 = *reinterpret_cast<const float4 *>(&s_taps[it + 2]);
                 const float gr[4] = {g01.x, g01.z, g23.x, g23.z};
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
             // edge block (history / end of block / ragged tail): same loop, but each lane decides per
             // 4-frame group whether it may use the vector load; only groups that straddle the block
             // boundary fall back to guarded scalar loads.
-            for (int it = lane * 4; it < cnt; it += kWave * 4) {
+            for (int it = lane0; it < cnt; it += LANE_STRIDE) {
                 const float4 g01 = *reinterpret_cast<const float4 *>(&s_taps[it]);
                 const float4 g23 = *reinterpret_cast<const float4 *>(&s_taps[it + 2]);
                 const float gr[4] = {g01.x, g01.z, g23.x, g23.z};
@@ -216,6 +224,23 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
         if (lane == r) {
             my_re = sr;
             my_im = si;
+        }
+    }
+    if constexpr (SPLITK) {
+        // fixed-order sum of the 8 waves' partial dot products (deterministic)
+        if (lane < CH_R) {
+            s_part[wave][lane][0] = my_re;
+            s_part[wave][lane][1] = my_im;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        if (lane < CH_R) {
+            my_re = my_im = 0.f;
+#pragma unroll
+            for (int w = 0; w < CH_WAVES; ++w) {
+                my_re += s_part[w][lane][0];
+                my_im += s_part[w][lane][1];
+            }
         }
     }
     if (lane < CH_R && o0 + lane < a.n_out) {
@@ -318,14 +343,25 @@ extern "C" int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, co
     a.sc_re = p->out_scale_re;
     a.sc_im = p->out_scale_im;
 
-    const int64_t blocks = (n_out + CH_OUT_PER_BLOCK - 1) / CH_OUT_PER_BLOCK;
+    // short launches cannot fill 256 CUs with 32-output blocks: split the taps across the block's waves instead
+    const bool splitk = n_out < 16384;
+    const int per_block = splitk ? CH_R : CH_OUT_PER_BLOCK;
+    const int64_t blocks = (n_out + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return fail_inval("too many outputs for one launch");
     dim3 grid(static_cast<unsigned>(blocks)), block(CH_THREADS);
     hipStream_t s = as_stream(stream);
-    switch (p->fmt) {
-        case IQA_FMT_S16: hipLaunchKernelGGL(k_channelize_v1<IQA_FMT_S16>, grid, block, 0, s, a); break;
-        case IQA_FMT_U8: hipLaunchKernelGGL(k_channelize_v1<IQA_FMT_U8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(k_channelize_v1<IQA_FMT_F32>, grid, block, 0, s, a); break;
+    if (splitk) {
+        switch (p->fmt) {
+            case IQA_FMT_S16: hipLaunchKernelGGL((k_channelize_v1<IQA_FMT_S16, true>), grid, block, 0, s, a); break;
+            case IQA_FMT_U8: hipLaunchKernelGGL((k_channelize_v1<IQA_FMT_U8, true>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((k_channelize_v1<IQA_FMT_F32, true>), grid, block, 0, s, a); break;
+        }
+    } else {
+        switch (p->fmt) {
+            case IQA_FMT_S16: hipLaunchKernelGGL((k_channelize_v1<IQA_FMT_S16, false>), grid, block, 0, s, a); break;
+            case IQA_FMT_U8: hipLaunchKernelGGL((k_channelize_v1<IQA_FMT_U8, false>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((k_channelize_v1<IQA_FMT_F32, false>), grid, block, 0, s, a); break;
+        }
     }
     return check_launch("k_channelize_v1");
 }

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_writer_clip(const float *a, long long n
         if (stats) {
             if (!uniform) {
                 while (seg + 1 < n_segs && seg_starts[seg + 1] <= idx) {
-                    if (run != 0.0) atomicAdd(&sumsq[seg], run);
+                    if (run != 0.0) atomicAdd(&sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
                     run = 0.0;
                     ++seg;
                 }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_writer_clip(const float *a, long long n
             run += static_cast<double>(v) * static_cast<double>(v);
         }
     }
-    if (stats && !uniform && run != 0.0) atomicAdd(&sumsq[seg], run);
+    if (stats && !uniform && run != 0.0) atomicAdd(&sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
     pk = wave_max(pk);
     const double wsq = uniform ? wave_sum(run) : 0.0;
     if ((threadIdx.x & 63) == 0) {
@@ -310,10 +310,11 @@ __global__ __launch_bounds__(256) void k_writer_clip(const float *a, long long n
     __syncthreads();
     if (threadIdx.x == 0) {
         if (peak_bits != nullptr) {
-            const float m = fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3]));
-            atomicMax(peak_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+            // non-negative floats order like their bit patterns; skip atomics that cannot raise the maximum
+            const unsigned int m = __float_as_uint(fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3])));
+            if (m > __hip_atomic_load(peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(peak_bits, m);
         }
-        if (uniform) atomicAdd(&sumsq[s_seg[0]], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
+        if (uniform) atomicAdd(&sumsq[s_seg[0] * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
     }
 }
 

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
                 if (stats) {
                     if (!uniform) {
                         while (seg + 1 < a.n_segs && a.segs[seg + 1] <= idx) {
-                            if (run != 0.0) atomicAdd(&a.sumsq[seg], run);
+                            if (run != 0.0) atomicAdd(&a.sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
                             run = 0.0;
                             ++seg;
                         }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
         }
     }
     if constexpr (SINK == K_CLIP) {
-        if (stats && !uniform && run != 0.0) atomicAdd(&a.sumsq[seg], run);
+        if (stats && !uniform && run != 0.0) atomicAdd(&a.sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
         pk = wave_max(pk);
         const double wsq = uniform ? wave_sum(run) : 0.0;
         if (lane == 0) {
@@ -240,9 +240,13 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
         }
         __syncthreads();
         if (tid == 0) {
-            if (a.peak_bits != nullptr)
-                atomicMax(a.peak_bits, __float_as_uint(fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3]))));
-            if (uniform) atomicAdd(&a.sumsq[s_seg[0]], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
+            if (a.peak_bits != nullptr) {
+                // thousands of atomics on one word serialise in L2 (~11 ns each): skip the ones that cannot
+                // raise the running maximum (a stale read only costs a redundant atomic, never a wrong result)
+                const unsigned int m = __float_as_uint(fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3])));
+                if (m > __hip_atomic_load(a.peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.peak_bits, m);
+            }
+            if (uniform) atomicAdd(&a.sumsq[s_seg[0] * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
         }
     }
 }

@@ -20,11 +20,11 @@ def rms_dbfs_of(audio_dev) -> float:
     n = int(audio_dev.numel())
     if n == 0:
         return float("nan")
-    sumsq = D.zeros(1, "float64")
+    sumsq = D.zeros(8, "float64")  # IQA_SUMSQ_SLOTS sub-slots
     seg = D.zeros(1, "int64")
     N.call("iqa_writer_clip", N.ptr(audio_dev), c_int64(n), c_void_p(0), N.ptr(seg), c_int64(1), N.ptr(sumsq),
            c_void_p(0), N.stream_ptr())
-    rms = math.sqrt(float(sumsq.item()) / n + 1e-18)
+    rms = math.sqrt(float(sumsq.sum().item()) / n + 1e-18)
     return 20.0 * math.log10(rms + 1e-12)
 
 

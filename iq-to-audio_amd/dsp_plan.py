@@ -7,6 +7,7 @@ of ``iq_order`` into taps/flags so that the kernel's inner loop is a plain dot p
 """
 from __future__ import annotations
 
+import functools
 import math
 from dataclasses import dataclass
 from fractions import Fraction
@@ -172,11 +173,28 @@ class MfmaPlan:
     unit: float  # value of one tap LSB
     c_re: float  # 128 * sum(T) over the real-output rows
     c_im: float
-    tq: np.ndarray  # int64 [128, Kpad] quantised taps T = 256*q1 + q2 (kept for tests)
+    tq: np.ndarray  # int32 [128, Kpad] quantised taps T = 256*q1 + q2 (kept for tests)
 
 
 def mfma_supported(plan: ChannelPlan) -> bool:
     return plan.fmt == "s16" and plan.taps_natural is not None and -(-plan.ntaps // plan.decimation) <= MFMA_Q
+
+
+@functools.lru_cache(maxsize=16)
+def _mfma_layout(ntaps: int, decimation: int):
+    """Index tables of the tap-fragment layout; they depend only on (L, D)."""
+    L, D = ntaps, decimation
+    ksteps = -(-2 * D // 32)
+    q = np.arange(1, MFMA_Q + 1, dtype=np.int64)[:, None]
+    rho = np.arange(D, dtype=np.int64)[None, :]
+    k = q * D - 1 - rho
+    ok = (k >= 0) & (k < L)
+    kc = np.clip(k, 0, L - 1)
+    lane = np.arange(64)
+    rows = (np.arange(4) * 32)[:, None] + (lane & 31)[None, :]  # [rt, lane]
+    cols = (32 * np.arange(ksteps))[:, None, None] + (16 * (lane >> 5))[None, :, None] + np.arange(16)[None, None, :]
+    flat = (rows[None, :, :, None] * (32 * ksteps) + cols[:, None, :, :]).astype(np.int64)  # [ks, rt, lane, j]
+    return ksteps, kc, ok, flat
 
 
 def plan_mfma(plan: ChannelPlan) -> MfmaPlan:
@@ -192,33 +210,27 @@ def plan_mfma(plan: ChannelPlan) -> MfmaPlan:
     if not mfma_supported(plan):
         raise ValueError("MFMA channelizer needs an int16 capture and ceil(ntaps/decimation) <= 64")
     g = plan.taps_natural
-    L, D = plan.ntaps, plan.decimation
-    ksteps = -(-2 * D // 32)
+    D = plan.decimation
+    ksteps, kc, ok, flat = _mfma_layout(plan.ntaps, D)
     kpad = 32 * ksteps
-    q = np.arange(1, MFMA_Q + 1, dtype=np.int64)[:, None]
-    rho = np.arange(D, dtype=np.int64)[None, :]
-    k = q * D - 1 - rho
-    ok = (k >= 0) & (k < L)
-    gk = np.where(ok, g[np.clip(k, 0, L - 1)], 0.0)
+    gk = g[kc]
+    gre = np.where(ok, gk.real, 0.0)
+    gim = np.where(ok, gk.imag, 0.0)
     a = np.zeros((2 * MFMA_Q, kpad), dtype=np.float64)
-    a[:MFMA_Q, 0 : 2 * D : 2] = gk.real
-    a[:MFMA_Q, 1 : 2 * D : 2] = -gk.imag
-    a[MFMA_Q:, 0 : 2 * D : 2] = gk.imag
-    a[MFMA_Q:, 1 : 2 * D : 2] = gk.real
-    amax = float(np.max(np.abs(a)))
+    a[:MFMA_Q, 0 : 2 * D : 2] = gre
+    a[:MFMA_Q, 1 : 2 * D : 2] = -gim
+    a[MFMA_Q:, 0 : 2 * D : 2] = gim
+    a[MFMA_Q:, 1 : 2 * D : 2] = gre
+    amax = float(np.abs(a).max())
     unit = amax / 32639.0 if amax > 0 else 1.0
-    t = np.rint(a / unit).astype(np.int64)
+    t = np.rint(a * (1.0 / unit)).astype(np.int32)
     q2 = ((t + 128) & 255) - 128
     q1 = (t - q2) >> 8
-    assert q1.min() >= -128 and q1.max() <= 127
-    pieces = np.stack([q1, q2]).astype(np.int8)  # [piece, row, kap]
-    lane = np.arange(64)
-    rows = (np.arange(4) * 32)[:, None] + (lane & 31)[None, :]  # [rt, lane]
-    cols = (32 * np.arange(ksteps))[:, None, None] + (16 * (lane >> 5))[None, :, None] + np.arange(16)[None, None, :]
-    # pieces[piece][rows[rt, lane], cols[ks, lane, j]] -> [piece, ks, rt, lane, j] -> [ks, rt, piece, lane, j]
-    frag = pieces[:, rows[None, :, :, None], cols[:, None, :, :]].transpose(1, 2, 0, 3, 4)
-    return MfmaPlan(ksteps, np.ascontiguousarray(frag), unit, 128.0 * float(t[:MFMA_Q].sum()),
-                    128.0 * float(t[MFMA_Q:].sum()), t)
+    frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
+    frag[:, :, 0] = q1.reshape(-1)[flat]
+    frag[:, :, 1] = q2.reshape(-1)[flat]
+    return MfmaPlan(ksteps, frag, unit, 128.0 * float(t[:MFMA_Q].sum(dtype=np.int64)),
+                    128.0 * float(t[MFMA_Q:].sum(dtype=np.int64)), t)
 
 
 def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decimation: int, ksteps: int):

@@ -304,6 +304,11 @@ class Channelizer:
         self.consumed = 0  # frames seen so far (global index of the next frame)
         self._hist = None  # device raw frames [L-1], same fmt
 
+    def plan_ahead(self) -> None:
+        """Do the host-side MFMA planning and tap upload now (otherwise done lazily by the first long block)."""
+        if self._kernel._mfma_range:
+            self._kernel._ensure_mfma()
+
     def outputs_for(self, n_frames: int) -> tuple[int, int]:
         """(m_first, n_out) for a block of ``n_frames`` frames appended now."""
         d = self.decimation
@@ -329,10 +334,72 @@ class Channelizer:
         return D.like_input(z, raw)
 
 
-def _mean_power(z_dev, skip: int) -> float:
-    out = D.zeros(1, "float64")
-    N.call("iqa_mean_power", N.ptr(z_dev), c_int64(z_dev.numel()), c_int64(skip), N.ptr(out), N.stream_ptr())
-    return float(out.item())
+def _mean_power_into(z_dev, skip: int, out_slot) -> None:
+    N.call("iqa_mean_power", N.ptr(z_dev), c_int64(z_dev.numel()), c_int64(skip), N.ptr(out_slot), N.stream_ptr())
+
+
+_PINNED_SCALARS = []
+
+
+def _pinned_scalars():
+    """A reusable pinned double[2] for probe read-backs (pin_memory() is slow: allocate once per slot)."""
+    torch = D.torch_mod()
+    for t in _PINNED_SCALARS:
+        if t[1] is None or t[1].query():
+            return t[0]
+    t = [torch.empty(2, dtype=torch.float64).pin_memory(), None]
+    _PINNED_SCALARS.append(t)
+    return t[0]
+
+
+class MixSignProbe:
+    """``choose_mix_sign`` split into an asynchronous launch and a blocking ``result()``, so the
+    caller can plan the channelizer while the two probes run."""
+
+    def __init__(self, warmup, sample_rate: float, freq_offset: float, taps: np.ndarray, decimation: int, *,
+                 fmt: str = "f32", iq_order: str = "iq"):
+        self._powers = None
+        self._valid = [False, False]
+        x_all, n_in = _as_frames(warmup, fmt)
+        if n_in == 0:
+            return
+        ntaps = len(taps)
+        max_len = max(int(sample_rate * 0.05), ntaps * 4, 131_072)
+        snippet_len = min(n_in, max_len)
+        if snippet_len < ntaps:
+            snippet_len = min(n_in, ntaps * 2)
+        x = x_all[:snippet_len] if x_all.is_complex() else x_all[: 2 * snippet_len]
+        decim = max(decimation, 1)
+        self._powers = D.zeros(2, "float64")
+        self._host = _pinned_scalars()
+        for i, sign in enumerate((1, -1)):
+            ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
+                             fmt=fmt, iq_order=iq_order)
+            z = ch.process(x)
+            if z.numel():
+                discard = min(ntaps, z.numel() // 4)
+                if z.numel() - discard == 0:
+                    discard = 0
+                _mean_power_into(z, discard, self._powers[i : i + 1])
+                self._valid[i] = True
+        self._host.copy_(self._powers, non_blocking=True)
+        self._done = D.torch_mod().cuda.Event()
+        self._done.record()
+        for t in _PINNED_SCALARS:
+            if t[0] is self._host:
+                t[1] = self._done
+
+    def result(self) -> int:
+        if self._powers is None:
+            return 1
+        self._done.synchronize()
+        host = self._host.numpy()
+        best_sign, best_power = 1, -np.inf
+        for i, sign in enumerate((1, -1)):
+            power = float(host[i]) if self._valid[i] else -np.inf
+            if power > best_power:
+                best_power, best_sign = power, sign
+        return best_sign
 
 
 def choose_mix_sign(warmup, sample_rate: float, freq_offset: float, taps: np.ndarray, decimation: int, *,
@@ -343,32 +410,9 @@ def choose_mix_sign(warmup, sample_rate: float, freq_offset: float, taps: np.nda
     from zero state, decimated (``[::D]``) and the mean power after dropping the first
     ``min(L, n/4)`` decimated samples is compared; strictly greater wins, ties give +1.
     ``warmup`` is complex64 (NumPy / tensor) or raw frames when ``fmt`` is 's16'/'u8'.
+    Both probes are enqueued before the single host read-back of the two powers.
     """
-    x_all, n_in = _as_frames(warmup, fmt)
-    if n_in == 0:
-        return 1
-    ntaps = len(taps)
-    max_len = max(int(sample_rate * 0.05), ntaps * 4, 131_072)
-    snippet_len = min(n_in, max_len)
-    if snippet_len < ntaps:
-        snippet_len = min(n_in, ntaps * 2)
-    x = x_all[:snippet_len] if x_all.is_complex() else x_all[: 2 * snippet_len]
-    decim = max(decimation, 1)
-    best_sign, best_power = 1, -np.inf
-    for sign in (1, -1):
-        ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
-                         fmt=fmt, iq_order=iq_order)
-        z = ch.process(x)
-        if z.numel() == 0:
-            power = -np.inf
-        else:
-            discard = min(ntaps, z.numel() // 4)
-            if z.numel() - discard == 0:
-                discard = 0
-            power = _mean_power(z, discard)
-        if power > best_power:
-            best_power, best_sign = power, sign
-    return best_sign
+    return MixSignProbe(warmup, sample_rate, freq_offset, taps, decimation, fmt=fmt, iq_order=iq_order).result()
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -425,15 +469,25 @@ class ChannelDemod:
         self.peak_dev = D.zeros(1, "float32")
         self.chunk_sumsq: list = []  # (device float64[n_chunks], counts)
 
+    def prepare(self, n: int, chunk_starts: np.ndarray):
+        """Upload / allocate everything ``process`` needs for a block of ``n`` samples ahead of time, so the
+        launches that follow a long kernel are not preceded by host-side copies."""
+        starts_dev = D.from_numpy(np.ascontiguousarray(chunk_starts, dtype=np.int64))
+        sumsq = D.zeros(len(chunk_starts) * 8, "float64")  # IQA_SUMSQ_SLOTS sub-slots per chunk
+        work = D.empty(int(N.lib().iqa_scan_workspace_bytes(n)), "uint8")
+        scratch = D.empty(n, "float32") if self._needs_scratch else None
+        self._prepared = (n, len(chunk_starts), starts_dev, sumsq, work, scratch)
+
     def process(self, z_dev, chunk_starts: np.ndarray, out_dev):
         """z_dev -> clipped float32 audio written into ``out_dev`` (len == len(z_dev))."""
         n = int(z_dev.numel())
         if n == 0:
             return
-        starts_dev = D.from_numpy(np.ascontiguousarray(chunk_starts, dtype=np.int64))
-        sumsq = D.zeros(len(chunk_starts), "float64")
-        work = D.empty(int(N.lib().iqa_scan_workspace_bytes(n)), "uint8")
-        scratch = D.empty(n, "float32") if self._needs_scratch else None
+        prep = getattr(self, "_prepared", None)
+        if prep is None or prep[0] != n or prep[1] != len(chunk_starts):
+            self.prepare(n, chunk_starts)
+        _, _, starts_dev, sumsq, work, scratch = self._prepared
+        self._prepared = None
         N.call("iqa_demodulate", byref(self.params), N.ptr(z_dev), c_int64(n), N.ptr(self.state_dev), N.ptr(starts_dev),
                c_int64(len(chunk_starts)), N.ptr(self.peak_dev), N.ptr(sumsq), N.ptr(out_dev), N.ptr(scratch), N.ptr(work),
                N.stream_ptr())
@@ -447,7 +501,7 @@ class ChannelDemod:
     def chunk_rms_dbfs(self) -> list[float]:
         out = []
         for sumsq, counts in self.chunk_sumsq:
-            for s, c in zip(sumsq.cpu().numpy(), counts):
+            for s, c in zip(sumsq.cpu().numpy().reshape(-1, 8).sum(axis=1), counts):
                 if c > 0:
                     out.append(20.0 * math.log10(math.sqrt(float(s) / float(c) + 1e-18) + 1e-12))
         return out
@@ -629,19 +683,25 @@ class ProcessingPipeline:
 
             warm = upload(0, min(chunk, total))
             _check_cancel("warm-up")
+            chan = None
             if cfg.mix_sign_override in (1, -1):
                 mix_sign = cfg.mix_sign_override
             else:
-                mix_sign = choose_mix_sign(warm, sample_rate, freq_offset, taps, decimation, fmt=info.fmt,
-                                           iq_order=cfg.iq_order)
+                # probes run on the GPU while the host plans the channelizer for the likely sign
+                probe = MixSignProbe(warm, sample_rate, freq_offset, taps, decimation, fmt=info.fmt, iq_order=cfg.iq_order)
+                chan = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=1,
+                                   decimation=decimation, fmt=info.fmt, iq_order=cfg.iq_order)
+                chan.plan_ahead()
+                mix_sign = probe.result()
             LOG.info("Selected mixer sign %d based on warm-up snippet.", mix_sign)
             output_path = cfg.output_path if cfg.output_path else self._default_output_path(info)
             if cfg.probe_only:
                 tracker.advance("ingest", float(warm.numel() // 2))
                 return ProcessingResult(probe, center_freq, target_freq, freq_offset, decimation, fs_channel, mix_sign, 0.0)
 
-            chan = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
-                               decimation=decimation, fmt=info.fmt, iq_order=cfg.iq_order)
+            if chan is None or mix_sign != 1:
+                chan = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
+                                   decimation=decimation, fmt=info.fmt, iq_order=cfg.iq_order)
             n_dec_total = -(-total // decimation)
             z_all = D.empty(n_dec_total, "complex64") if (pass_through or cfg.dump_iq_path) else None
             audio_all = None if pass_through else D.empty(n_dec_total, "float32")
@@ -656,6 +716,9 @@ class ProcessingPipeline:
                 tracker.advance("ingest", float(n))
                 tracker.status(f"channel @ {done}")
                 m_first, n_out = chan.outputs_for(n)
+                if not pass_through and n_out:
+                    starts = P.chunk_output_starts(chunk, decimation, done, n)
+                    demod.prepare(n_out, starts)
                 z = chan.process(raw)
                 tracker.advance("channel", float(n_out))
                 if z_all is not None and n_out:
@@ -663,7 +726,6 @@ class ProcessingPipeline:
                     if cfg.dump_iq_path:
                         tracker.advance("dump_iq", float(n_out))
                 if not pass_through and n_out:
-                    starts = P.chunk_output_starts(chunk, decimation, done, n)
                     demod.process(z, starts, audio_all[pos_dec : pos_dec + n_out])
                 tracker.advance("demod", float(n_out))
                 _check_cancel("encode")
