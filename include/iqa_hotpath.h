@@ -117,9 +117,11 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
  */
 typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
-    int32_t reserved;
+    int32_t reserved;          /* diagnostics flags, 0 in production */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
+    void *debug_stamps;        /* NULL in production; diagnostics builds write per-wave cycle stamps here
+                                * (64 B per wave) when bit 1 of `reserved` is set */
 } iqa_mfma_params;
 int64_t iqa_mfma_afrag_bytes(int32_t decimation);
 int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,

@@ -32,13 +32,15 @@
 //   A[row=l&31][k=16(l>>5)+j], B[k=16(l>>5)+j][col=l&31], C: col=l&31, row=(r&3)+8(r>>2)+4(l>>5).
 #include "common.h"
 
+#include <type_traits>
+
 namespace iqa {
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef v4i_t v4i_a4 __attribute__((aligned(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 
-constexpr int MF_WAVES = 4;
+constexpr int MF_WAVES = 8;  // one block per CU, two waves per SIMD, tap fragments shared by all eight
 constexpr int MF_THREADS = MF_WAVES * kWave;
 constexpr int MF_Q = 64;          // q slots per output component (needs ceil(L/D) <= 64)
 constexpr int MF_ROWTILES = 4;    // 2 components x 64 q = 128 rows
@@ -49,7 +51,8 @@ struct MfmaArgs {
     const int *raw;      // capture frames as dwords (lo half = I, hi half = Q)
     float2 *out;         // out[i] = z[m_lo + i]
     long long consumed, m_lo, n_out;
-    int D, ksteps, range;
+    int D, ksteps, range, debug;
+    unsigned long long *stamps;  // diagnostics only (debug bit 1): per-wave cycle anatomy
     double unit, c_re, c_im;
     int conj_sum, rotate;
     unsigned long long rot_step, rot_base;
@@ -68,65 +71,143 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs 
     const int tiles = (cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
     const int acc_len = tiles * 32 + MF_Q + 4;
 
+    const bool stamp = (a.debug & 2) && a.stamps != nullptr;
+    unsigned long long t_begin = 0, t_loop0 = 0, t_scatter = 0, t_loop1 = 0;
+    if (stamp) t_begin = __builtin_amdgcn_s_memtime();
     v4i_t *s_a = reinterpret_cast<v4i_t *>(smem);
     int *s_acc = reinterpret_cast<int *>(smem + static_cast<size_t>(a.ksteps) * MF_KSTEP_BYTES);
     // s_acc layout: [S1re | S1im | S2re | S2im], each acc_len ints
-    for (int i = tid; i < a.ksteps * (MF_KSTEP_BYTES / 16); i += MF_THREADS) s_a[i] = a.afrag[i];
-    for (int i = tid; i < 4 * acc_len; i += MF_THREADS) s_acc[i] = 0;
-    __syncthreads();
-
-    for (int t = wave; t < tiles; t += MF_WAVES) {
-        const long long b = m0 - MF_Q + t * 32 + col;               // this lane's data column (global row index)
-        const int *rowp = a.raw + (b * a.D + 1 - a.consumed) + 8 * h;  // dword index of kap = 16h
-        v16i_t acc1[MF_ROWTILES], acc2[MF_ROWTILES];
+    {
+        // tap fragments -> LDS, eight loads in flight per thread (a plain load/store loop serialises on latency)
+        const int n16 = a.ksteps * (MF_KSTEP_BYTES / 16);
+        for (int i0f = tid; i0f < n16; i0f += MF_THREADS * 8) {
+            v4i_t tmp[8];
 #pragma unroll
-        for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-            acc1[rt] = v16i_t{0};
-            acc2[rt] = v16i_t{0};
-        }
-        v4i_t d0 = *reinterpret_cast<const v4i_a4 *>(rowp);
-        v4i_t d1 = *reinterpret_cast<const v4i_a4 *>(rowp + 4);
-        for (int ks = 0; ks < a.ksteps; ++ks) {
-            // prefetch the next k step's data (the last iteration re-reads the current one: in bounds)
-            const int *nxt = rowp + 16 * ((ks + 1 < a.ksteps) ? ks + 1 : ks);
-            const v4i_t n0 = *reinterpret_cast<const v4i_a4 *>(nxt);
-            const v4i_t n1 = *reinterpret_cast<const v4i_a4 *>(nxt + 4);
-            // split the 16 int16 values into high bytes and (low bytes - 128)
-            v4i_t hi, lo;
-            hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
-            hi.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x07050301);
-            hi.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x07050301);
-            hi.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x07050301);
-            lo.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200) ^ 0x80808080;
-            lo.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x06040200) ^ 0x80808080;
-            lo.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200) ^ 0x80808080;
-            lo.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x06040200) ^ 0x80808080;
-            const v4i_t *fa = s_a + ks * (MF_KSTEP_BYTES / 16) + lane;
-#pragma unroll
-            for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-                const v4i_t q1 = fa[(rt * 2 + 0) * 64];
-                const v4i_t q2 = fa[(rt * 2 + 1) * 64];
-                acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, hi, acc1[rt], 0, 0, 0);
-                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, lo, acc2[rt], 0, 0, 0);
-                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q2, hi, acc2[rt], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0f + u * MF_THREADS;
+                tmp[u] = (i < n16) ? a.afrag[i] : v4i_t{0, 0, 0, 0};
             }
-            d0 = n0;
-            d1 = n1;
-        }
-        // diagonal scatter: row (comp, qidx) of column b adds into position col_local + qidx + 1
-        int *base = s_acc + (t * 32 + col + 4 * h + 1);
 #pragma unroll
-        for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-            int *p1 = base + (rt >> 1) * acc_len + (rt & 1) * 32;  // S1re / S1im
-            int *p2 = p1 + 2 * acc_len;                            // S2re / S2im
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                atomicAdd(p1 + off, acc1[rt][r]);
-                atomicAdd(p2 + off, acc2[rt][r]);
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0f + u * MF_THREADS;
+                if (i < n16) s_a[i] = tmp[u];
             }
         }
     }
+    for (int i = tid; i < 4 * acc_len; i += MF_THREADS) s_acc[i] = 0;
+    __syncthreads();
+
+    // Software pipeline over the flat sequence of (tile, k step) pairs of this wave, unrolled by two with
+    // two static data slots A/B: right after a slot has been consumed (byte split) the load of the pair two
+    // steps ahead is issued into the SAME registers, and each row tile's tap fragments for the next pair
+    // are requested from LDS right after that row tile's three MFMAs.  No register is copied while its
+    // load is in flight (a copy would force the wait the pipeline is there to avoid).
+    int pf_tile = wave, pf_ks = 0;
+    auto row_ptr = [&](int tile) -> const int * {
+        const long long b = m0 - MF_Q + tile * 32 + col;  // this lane's data column (global row index)
+        return a.raw + (b * a.D + 1 - a.consumed) + 8 * h;  // dword index of kap = 16h
+    };
+    const int *pf_row = row_ptr(min(pf_tile, tiles - 1));
+#define MF_LOAD_PAIR(X0, X1)                                                        \
+    {                                                                               \
+        X0 = *reinterpret_cast<const v4i_a4 *>(pf_row + 16 * pf_ks);                \
+        X1 = *reinterpret_cast<const v4i_a4 *>(pf_row + 16 * pf_ks + 4);            \
+        if (++pf_ks == a.ksteps) {                                                  \
+            pf_ks = 0;                                                              \
+            pf_tile += MF_WAVES;                                                    \
+            pf_row = row_ptr(min(pf_tile, tiles - 1)); /* past the end: re-read */  \
+        }                                                                           \
+    }
+    v4i_t a0, a1, b0, b1;
+    MF_LOAD_PAIR(a0, a1);
+    MF_LOAD_PAIR(b0, b1);
+    v4i_t fr[2 * MF_ROWTILES];
+    {
+        const v4i_t *fa = s_a + lane;
+#pragma unroll
+        for (int i = 0; i < 2 * MF_ROWTILES; ++i) fr[i] = fa[i * 64];
+    }
+    v16i_t acc1[MF_ROWTILES], acc2[MF_ROWTILES];
+#pragma unroll
+    for (int rt = 0; rt < MF_ROWTILES; ++rt) {
+        acc1[rt] = v16i_t{0};
+        acc2[rt] = v16i_t{0};
+    }
+    const v16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (stamp) t_loop0 = __builtin_amdgcn_s_memtime();
+    int t = wave, ks = 0;  // the pair being multiplied
+    const bool skip_scatter = (a.debug & 1) != 0;
+
+#define MF_PAIR(X0, X1)                                                                              \
+    {                                                                                                \
+        v4i_t hi, lo;                                                                                \
+        hi.x = __builtin_amdgcn_perm(X0.y, X0.x, 0x07050301);                                        \
+        hi.y = __builtin_amdgcn_perm(X0.w, X0.z, 0x07050301);                                        \
+        hi.z = __builtin_amdgcn_perm(X1.y, X1.x, 0x07050301);                                        \
+        hi.w = __builtin_amdgcn_perm(X1.w, X1.z, 0x07050301);                                        \
+        lo.x = __builtin_amdgcn_perm(X0.y, X0.x, 0x06040200) ^ 0x80808080;                           \
+        lo.y = __builtin_amdgcn_perm(X0.w, X0.z, 0x06040200) ^ 0x80808080;                           \
+        lo.z = __builtin_amdgcn_perm(X1.y, X1.x, 0x06040200) ^ 0x80808080;                           \
+        lo.w = __builtin_amdgcn_perm(X1.w, X1.z, 0x06040200) ^ 0x80808080;                           \
+        MF_LOAD_PAIR(X0, X1);                                                                        \
+        const int kn = (ks + 1 < a.ksteps) ? ks + 1 : 0;                                             \
+        const v4i_t *fa = s_a + kn * (MF_KSTEP_BYTES / 16) + lane;                                   \
+        if (ks == 0) { /* first step of a tile: C = 0 constant, no accumulator clearing needed */     \
+            _Pragma("unroll") for (int rt = 0; rt < MF_ROWTILES; ++rt)                               \
+            {                                                                                        \
+                acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], hi, zero16, 0, 0, 0);   \
+                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], lo, zero16, 0, 0, 0);   \
+                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt + 1], hi, acc2[rt], 0, 0, 0); \
+                fr[2 * rt] = fa[(2 * rt) * 64];                                                      \
+                fr[2 * rt + 1] = fa[(2 * rt + 1) * 64];                                              \
+            }                                                                                        \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int rt = 0; rt < MF_ROWTILES; ++rt)                               \
+            {                                                                                        \
+                acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], hi, acc1[rt], 0, 0, 0); \
+                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], lo, acc2[rt], 0, 0, 0); \
+                acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt + 1], hi, acc2[rt], 0, 0, 0); \
+                fr[2 * rt] = fa[(2 * rt) * 64];                                                      \
+                fr[2 * rt + 1] = fa[(2 * rt + 1) * 64];                                              \
+            }                                                                                        \
+        }                                                                                            \
+        if (++ks == a.ksteps) { /* tile complete: diagonal scatter into the block's S1/S2 arrays */   \
+            unsigned long long ts0 = 0;                                                              \
+            if (stamp) ts0 = __builtin_amdgcn_s_memtime();                                           \
+            if (!skip_scatter) {                                                                     \
+                int *base = s_acc + (t * 32 + col + 4 * h + 1);                                      \
+                _Pragma("unroll") for (int rt = 0; rt < MF_ROWTILES; ++rt)                           \
+                {                                                                                    \
+                    int *p1 = base + (rt >> 1) * acc_len + (rt & 1) * 32;                            \
+                    int *p2 = p1 + 2 * acc_len;                                                      \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                   \
+                    {                                                                                \
+                        const int off = (r & 3) + 8 * (r >> 2);                                      \
+                        atomicAdd(p1 + off, acc1[rt][r]);                                            \
+                        atomicAdd(p2 + off, acc2[rt][r]);                                            \
+                    }                                                                                \
+                }                                                                                    \
+            } else {                                                                                 \
+                _Pragma("unroll") for (int rt = 0; rt < MF_ROWTILES; ++rt)                           \
+                    asm volatile("" ::"v"(acc1[rt]), "v"(acc2[rt]));                                 \
+            }                                                                                        \
+            if (stamp) {                                                                             \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+                t_scatter += __builtin_amdgcn_s_memtime() - ts0;                                     \
+            }                                                                                        \
+            ks = 0;                                                                                  \
+            t += MF_WAVES;                                                                           \
+        }                                                                                            \
+    }
+
+    while (t < tiles) {
+        MF_PAIR(a0, a1);
+        if (t >= tiles) break;
+        MF_PAIR(b0, b1);
+    }
+#undef MF_PAIR
+#undef MF_LOAD_PAIR
+    if (stamp) t_loop1 = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
     // emission: output m0+i sits at position 64+i
@@ -149,6 +230,16 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs 
             yi = my_re * sf + my_im * cf;
         }
         a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+    }
+    if (stamp && lane == 0) {
+        // stamps go to a buffer nothing else reads: {prologue, main loop incl. scatter, scatter only, tail, tiles}
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = a.stamps + (static_cast<size_t>(blockIdx.x) * MF_WAVES + wave) * 8;
+        o[0] = t_loop0 - t_begin;
+        o[1] = t_loop1 - t_loop0;
+        o[2] = t_scatter;
+        o[3] = t_end - t_loop1;
+        o[4] = static_cast<unsigned long long>((tiles - wave + MF_WAVES - 1) / MF_WAVES);
     }
 }
 
@@ -207,6 +298,8 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     a.D = static_cast<int>(D);
     a.ksteps = ksteps;
     a.range = range;
+    a.debug = q->reserved;
+    a.stamps = static_cast<unsigned long long *>(q->debug_stamps);
     a.unit = q->unit;
     a.c_re = q->c_re;
     a.c_im = q->c_im;

@@ -165,10 +165,10 @@ class _ChannelKernel:
         self._mfma_range = 0
         if self.use_mfma and P.mfma_supported(plan):
             afrag_bytes = int(N.lib().iqa_mfma_afrag_bytes(plan.decimation))
-            budget = 80 * 1024 if afrag_bytes <= 56 * 1024 else 160 * 1024  # two blocks per CU when they fit
-            rng = ((budget - afrag_bytes) // 16 - 160) // 32 * 32
-            if rng >= 256:
-                self._mfma_range = min(rng, 2048)
+            # one 8-wave block per CU owns all 160 KiB of LDS: tap fragments + 16 B per output of accumulators
+            rng = ((160 * 1024 - afrag_bytes) // 16 - 160) // 32 * 32
+            if rng >= 512:
+                self._mfma_range = min(rng, 6144)
 
     def _ensure_mfma(self):
         if self.mfma is None:
@@ -178,6 +178,14 @@ class _ChannelKernel:
             self.mfma_params = N.MfmaParams(outputs_per_block=self._mfma_range, reserved=0, unit=mp.unit,
                                             c_re=mp.c_re, c_im=mp.c_im)
         return self.mfma
+
+    def _block_outputs(self, n_out: int) -> int:
+        """Outputs per block for a launch of ``n_out`` outputs: as large as LDS allows, but chosen so that the
+        number of blocks is a multiple of the 256 CUs (one block per CU, no ragged last round)."""
+        rmax = self._mfma_range
+        rounds = max(1, -(-n_out // (256 * rmax)))
+        per = -(-n_out // (256 * rounds))
+        return int(min(rmax, max(512, -(-per // 32) * 32)))
 
     def _valu(self, raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev):
         if n_out > 0:
@@ -197,6 +205,7 @@ class _ChannelKernel:
                 self._ensure_mfma()
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
                 self.last_kernel = "k_channelize_mfma_s16"
+                self.mfma_params.outputs_per_block = self._block_outputs(m_b - m_a)
                 if events:
                     events[0].record()
                 N.call("iqa_channelize_mfma", byref(self.params), byref(self.mfma_params), N.ptr(self.afrag_dev),

@@ -1,35 +1,38 @@
-"""Scratch check used while bringing up the int8-MFMA channelizer: MFMA vs VALU kernel vs oracle, and timing."""
+"""Scratch: MFMA channelizer timing experiments on the full C2 workload (debug flags skip parts of the kernel)."""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 import iq_to_audio_amd as A
 from iq_to_audio_amd import _dev as D, processing as PR
-from oracle import cpu_ref as O
+from iq_to_audio_amd.benchmark import synthetic_iq_s16
 
-def rms(a): return float(np.sqrt(np.mean(np.abs(a.astype(np.complex128))**2)))
+fs, d, bw, f_off = 10e6, 104, 12500., 25e3
+n_total = 600_000_000
+host = synthetic_iq_s16(fs, 1.0, f_off).reshape(-1)
+raw = torch.from_numpy(host).to("cuda").repeat(60)[: 2 * n_total].contiguous()
+taps = A.design_channel_filter(fs, bw, d)
+z = D.empty(-(-n_total // d), "complex64")
+import os
+for dbg in [int(x) for x in os.environ.get('DBG', '0,1').split(',')]:
+    ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
+    ch.plan_ahead(); ch._kernel.mfma_params.reserved = dbg
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for it in range(6):
+        ch.consumed = 0; ch._hist = None
+        ch.process(raw, out_dev=z, events=(e0, e1)); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    print(f"debug={dbg}: kernel ms {[round(t,3) for t in ts]}  -> {n_total/np.median(ts)/1e6:.0f} GS/s")
 
-for fs, d, bw, nfr in ((2.5e6, 26, 12500., 3_000_000), (10e6, 104, 12500., 12_000_000)):
-    f_off = 25e3
-    raw = O.synth_capture_s16(fs, nfr / fs, f_off).reshape(-1)
-    taps = A.design_channel_filter(fs, bw, d)
-    x = D.to_device(raw, "int16")
-    outs = {}
-    for use in (False, True):
-        PR._ChannelKernel.use_mfma = use
-        ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
-        z = ch.process(x); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            ch2 = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
-            z2 = ch2.process(x)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-        outs[use] = z.cpu().numpy()
-        same = bool(torch.equal(z, z2))
-        print(f"fs={fs/1e6}M D={d} L={len(taps)} mfma={use} has_mfma={ch._kernel.mfma is not None}: {dt*1e3:.3f} ms -> {nfr/dt/1e9:.1f} GS/s; reproducible={same}")
-    n_cpu = min(nfr, 2_000_000)
-    want = O.decimate(O.overlap_save(O.nco_mix(O.ingest_to_complex64(raw[:2*n_cpu], 's16'), O.NcoState(f_off, fs), 1), O.OverlapSaveState(taps, 65536)), O.DecimState(d))
-    k = want.size
-    print("  valu vs oracle rms", rms(outs[False][:k] - want), "max", np.abs(outs[False][:k] - want).max())
-    print("  mfma vs oracle rms", rms(outs[True][:k] - want), "max", np.abs(outs[True][:k] - want).max())
-    print("  mfma vs valu  rms", rms(outs[True] - outs[False]), "max", np.abs(outs[True] - outs[False]).max(), "n", outs[True].size)
+# cycle anatomy from in-kernel stamps (diagnostic build path, debug bit 1)
+ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
+ch.plan_ahead()
+nblk = -(-(n_total // d) // 512) + 2
+st = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device="cuda")
+ch._kernel.mfma_params.reserved = 2
+ch._kernel.mfma_params.debug_stamps = st.data_ptr()
+ch.process(raw, out_dev=z); torch.cuda.synchronize()
+s = st.cpu().numpy().reshape(-1, 8)
+s = s[s[:, 4] > 0]
+print("outputs/block:", ch._kernel.mfma_params.outputs_per_block); print("waves:", len(s), "median cycles: prologue %d, loop %d (scatter %d), tail %d, tiles/wave %d" % tuple(np.median(s[:, i]) for i in range(5)))
+print("per tile: loop %.0f cycles, of which scatter %.0f; ideal MFMA per tile %d" % (np.median(s[:, 1] / s[:, 4]), np.median(s[:, 2] / s[:, 4]), 7 * 12 * 32))
