@@ -111,9 +111,14 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
  * dense integer GEMM on the matrix cores with exact int32 accumulation (see channelize_mfma.hip).
  * It covers only outputs whose whole read range lies inside raw_dev[0, n_frames): columns
  * (m_first-64)*D+1 ... ; the caller runs iqa_channelize for the few outputs at the block's head
- * (history) and tail.  Requires ceil(ntaps/decimation) <= 64.
- *   afrag_dev : tap fragments, iqa_mfma_afrag_bytes(D) bytes, layout [kstep][rowtile 4][piece 2][lane 64][16 B]
+ * (history) and tail.
+ *   afrag_dev : tap fragments of THIS pass, k_count*8192 bytes, layout [kstep][rowtile 4][piece 2][lane 64][16 B]
  *               (host: dsp_plan.plan_mfma); unit/c_re/c_im from the same quantisation.
+ * One call is one PASS over (q-group, k-step range).  A filter with ceil(L/D) <= 64 whose fragments fit
+ * LDS needs a single pass (q_group 0, all k steps, finalize 1).  Longer filters are split into q-groups of
+ * 64 tap rows (each pass reads the capture again, shifted by 64*q_group rows), larger decimations into k-step
+ * ranges (each pass reads its own part of every row); passes chain their raw sums through
+ * partial_out_dev -> partial_in_dev (double2[n_out]) and the last pass (finalize 1) rotates, scales, stores z.
  */
 typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
@@ -122,6 +127,12 @@ typedef struct {
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
     void *debug_stamps;        /* NULL in production; diagnostics builds write per-wave cycle stamps here
                                 * (64 B per wave) when bit 1 of `reserved` is set */
+    int32_t q_group;           /* tap rows 64*q_group+1 .. 64*q_group+64 */
+    int32_t k_first;           /* first k step (32 int16 values each) of this pass */
+    int32_t k_count;           /* k steps in this pass; 0 = all remaining */
+    int32_t finalize;          /* 1 = last pass */
+    const void *partial_in_dev;  /* double2[n_out] raw sums of the previous passes, or NULL */
+    void *partial_out_dev;       /* double2[n_out], written when finalize == 0 */
 } iqa_mfma_params;
 int64_t iqa_mfma_afrag_bytes(int32_t decimation);
 int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,

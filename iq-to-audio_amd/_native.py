@@ -43,7 +43,8 @@ class MfmaParams(ctypes.Structure):
     """``iqa_mfma_params`` (include/iqa_hotpath.h)."""
 
     _fields_ = [("outputs_per_block", c_int32), ("reserved", c_int32), ("unit", c_double), ("c_re", c_double),
-                ("c_im", c_double), ("debug_stamps", c_void_p)]
+                ("c_im", c_double), ("debug_stamps", c_void_p), ("q_group", c_int32), ("k_first", c_int32),
+                ("k_count", c_int32), ("finalize", c_int32), ("partial_in_dev", c_void_p), ("partial_out_dev", c_void_p)]
 
 
 class DemodParams(ctypes.Structure):

@@ -52,6 +52,11 @@ struct MfmaArgs {
     float2 *out;         // out[i] = z[m_lo + i]
     long long consumed, m_lo, n_out;
     int D, ksteps, range, debug;
+    int k_first;      // first k step of this pass (K split over passes when the tap fragments exceed LDS)
+    int col_shift;    // 64 * q-group of this pass (filters with ceil(L/D) > 64 are split into q-groups)
+    int finalize;     // 1: add partial_in, rotate/scale and store z; 0: store the raw sums to partial_out
+    const double2 *partial_in;
+    double2 *partial_out;
     unsigned long long *stamps;  // diagnostics only (debug bit 1): per-wave cycle anatomy
     double unit, c_re, c_im;
     int conj_sum, rotate;
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs 
     // load is in flight (a copy would force the wait the pipeline is there to avoid).
     int pf_tile = wave, pf_ks = 0;
     auto row_ptr = [&](int tile) -> const int * {
-        const long long b = m0 - MF_Q + tile * 32 + col;  // this lane's data column (global row index)
-        return a.raw + (b * a.D + 1 - a.consumed) + 8 * h;  // dword index of kap = 16h
+        const long long b = m0 - MF_Q - a.col_shift + tile * 32 + col;  // this lane's data column (global row index)
+        return a.raw + (b * a.D + 1 - a.consumed) + 16 * a.k_first + 8 * h;  // dword index of kap = 32 k_first + 16h
     };
     const int *pf_row = row_ptr(min(pf_tile, tiles - 1));
 #define MF_LOAD_PAIR(X0, X1)                                                        \
@@ -215,8 +220,19 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs 
         const int pos = MF_Q + i;
         const double s1r = s_acc[pos], s1i = s_acc[acc_len + pos];
         const double s2r = s_acc[2 * acc_len + pos], s2i = s_acc[3 * acc_len + pos];
-        float my_re = static_cast<float>((s1r * 65536.0 + s2r * 256.0 + a.c_re) * a.unit);
-        float my_im = static_cast<float>((s1i * 65536.0 + s2i * 256.0 + a.c_im) * a.unit);
+        double d_re = (s1r * 65536.0 + s2r * 256.0 + a.c_re) * a.unit;
+        double d_im = (s1i * 65536.0 + s2i * 256.0 + a.c_im) * a.unit;
+        if (a.partial_in != nullptr) {
+            const double2 pr = a.partial_in[i0 + i];
+            d_re += pr.x;
+            d_im += pr.y;
+        }
+        if (!a.finalize) {
+            a.partial_out[i0 + i] = make_double2(d_re, d_im);
+            continue;
+        }
+        float my_re = static_cast<float>(d_re);
+        float my_im = static_cast<float>(d_im);
         if (a.conj_sum) my_im = -my_im;
         float yr = my_re, yi = my_im;
         if (a.rotate) {
@@ -249,6 +265,7 @@ using namespace iqa;
 
 extern "C" int64_t iqa_mfma_afrag_bytes(int32_t decimation)
 {
+    // bytes of tap fragments for ALL k steps of one q-group (a pass may use a sub-range of k steps)
     if (decimation < 1) return 0;
     const int64_t ksteps = (2 * static_cast<int64_t>(decimation) + 31) / 32;
     return ksteps * MF_KSTEP_BYTES;
@@ -262,11 +279,15 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     if (p->fmt != IQA_FMT_S16) return fail_inval("the MFMA channelizer takes int16 captures only");
     if (p->ntaps <= 0 || p->decimation < 1) return fail_inval("bad ntaps/decimation");
     const int64_t D = p->decimation;
-    if ((static_cast<int64_t>(p->ntaps) + D - 1) / D > MF_Q) return fail_inval("ceil(ntaps/decimation) must be <= 64");
     if (n_out < 0 || n_frames < 0 || consumed < 0 || m_first < 0) return fail_inval("negative size");
     if (n_out == 0) return IQA_OK;
     if (!afrag_dev || !raw_dev || !z_out_dev) return fail_inval("NULL device pointer");
-    const int ksteps = static_cast<int>((2 * D + 31) / 32);
+    const int ksteps_all = static_cast<int>((2 * D + 31) / 32);
+    const int k_first = q->k_first;
+    const int ksteps = q->k_count > 0 ? q->k_count : ksteps_all - k_first;
+    if (k_first < 0 || ksteps <= 0 || k_first + ksteps > ksteps_all) return fail_inval("bad k-step range");
+    if (q->q_group < 0) return fail_inval("bad q group");
+    if (!q->finalize && !q->partial_out_dev) return fail_inval("non-final pass needs partial_out_dev");
     int range = q->outputs_per_block;
     if (range <= 0 || (range & 31)) return fail_inval("outputs_per_block must be a positive multiple of 32");
     // every frame the kernel touches must lie inside [0, n_frames): columns b in [m_first-64, last], each read
@@ -274,14 +295,15 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     const int64_t blocks = (n_out + range - 1) / range;
     const int64_t last_cnt = n_out - (blocks - 1) * range;
     const int64_t last_tiles = (last_cnt + 63 + 31) / 32;
-    const int64_t b_min = m_first - MF_Q;
-    const int64_t b_max = m_first + (blocks - 1) * range - MF_Q + last_tiles * 32 - 1;
+    const int64_t col_shift = static_cast<int64_t>(MF_Q) * q->q_group;
+    const int64_t b_min = m_first - MF_Q - col_shift;
+    const int64_t b_max = m_first + (blocks - 1) * range - MF_Q - col_shift + last_tiles * 32 - 1;
     const int64_t f_min = b_min * D + 1 - consumed;
-    const int64_t f_max = b_max * D + 1 - consumed + 16LL * ksteps - 1;
+    const int64_t f_max = b_max * D + 1 - consumed + 16LL * (k_first + ksteps) - 1;
     // full blocks are also bounded by their own tile count
     const int64_t full_tiles = (static_cast<int64_t>(range) + 63 + 31) / 32;
-    const int64_t b_max_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q + full_tiles * 32 - 1 : b_max;
-    const int64_t f_max_full = b_max_full * D + 1 - consumed + 16LL * ksteps - 1;
+    const int64_t b_max_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q - col_shift + full_tiles * 32 - 1 : b_max;
+    const int64_t f_max_full = b_max_full * D + 1 - consumed + 16LL * (k_first + ksteps) - 1;
     if (f_min < 0 || f_max >= n_frames || f_max_full >= n_frames)
         return fail_inval("MFMA channelizer range reads outside the block (use iqa_channelize for the edges)");
     const int64_t acc_len = full_tiles * 32 + MF_Q + 4;
@@ -298,6 +320,11 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     a.D = static_cast<int>(D);
     a.ksteps = ksteps;
     a.range = range;
+    a.k_first = k_first;
+    a.col_shift = static_cast<int>(col_shift);
+    a.finalize = q->finalize;
+    a.partial_in = static_cast<const double2 *>(q->partial_in_dev);
+    a.partial_out = static_cast<double2 *>(q->partial_out_dev);
     a.debug = q->reserved;
     a.stamps = static_cast<unsigned long long *>(q->debug_stamps);
     a.unit = q->unit;

@@ -351,7 +351,9 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
     const long long g_per = ((g_total + split - 1) / split + 3) & ~3LL;
     const long long g_lo = part * g_per, g_hi = min(g_total, g_lo + g_per);
     if (g_lo >= g_hi) return;
-    const int p = static_cast<int>(((j0 + jj0) * down) % up);
+    const long long c0 = (j0 + jj0) * down;
+    const long long q0 = c0 / up;  // the only 64-bit division: successive outputs of a row advance q by `down`
+    const int p = static_cast<int>(c0 - q0 * up);
     const double *row = table + static_cast<long long>(p) * row_len;
     double h[RS_MAX_NI];
 #pragma unroll
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
     for (long long g = g_lo + quarter; g < g_hi + quarter; g += 4) {  // all quarters iterate together
         const bool live = g < g_hi;
         const long long jj = jj0 + g * up;
-        const long long q = ((j0 + jj) * down) / up;
+        const long long q = q0 + g * down;
         double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < RS_MAX_NI; ++i) {

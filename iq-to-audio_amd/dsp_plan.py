@@ -161,7 +161,27 @@ def plan_channel(
     )
 
 
-MFMA_Q = 64  # q slots per output component in the int8-MFMA kernel
+MFMA_Q = 64  # q slots (tap rows) per pass and output component in the int8-MFMA kernel
+MFMA_KSTEP_BYTES = 8192  # tap fragments per k step: 4 row tiles x 2 pieces x 64 lanes x 16 B
+MFMA_MAX_KSTEPS_PER_PASS = 16  # 128 KiB of fragments leaves room for >= 1888 outputs of accumulators in LDS
+
+
+@dataclass
+class MfmaGroup:
+    """Tap rows 64*g+1 .. 64*g+64 of the filter, quantised on their own scale."""
+
+    afrag: np.ndarray  # int8 [ksteps, 4, 2, 64, 16] tap fragments in MFMA lane order
+    unit: float  # value of one tap LSB
+    tq: np.ndarray  # int32 [128, Kpad] quantised taps T = 256*q1 + q2
+
+
+@dataclass
+class MfmaPass:
+    group: int
+    k_first: int
+    k_count: int
+    c_re: float  # 128 * sum(T) over the real-output rows and this pass's k range (low-byte bias)
+    c_im: float
 
 
 @dataclass
@@ -169,23 +189,41 @@ class MfmaPlan:
     """Host-side operands of ``iqa_channelize_mfma`` (see csrc/channelize_mfma.hip)."""
 
     ksteps: int
-    afrag: np.ndarray  # int8 [ksteps, 4, 2, 64, 16] tap fragments in MFMA lane order
-    unit: float  # value of one tap LSB
-    c_re: float  # 128 * sum(T) over the real-output rows
-    c_im: float
-    tq: np.ndarray  # int32 [128, Kpad] quantised taps T = 256*q1 + q2 (kept for tests)
+    groups: list
+    passes: list
+
+    # single-pass conveniences (tests, and the common ceil(L/D) <= 64, D <= 256 case)
+    @property
+    def afrag(self):
+        return self.groups[0].afrag
+
+    @property
+    def unit(self):
+        return self.groups[0].unit
+
+    @property
+    def tq(self):
+        return self.groups[0].tq
+
+    @property
+    def c_re(self):
+        return sum(p.c_re for p in self.passes if p.group == 0)
+
+    @property
+    def c_im(self):
+        return sum(p.c_im for p in self.passes if p.group == 0)
 
 
 def mfma_supported(plan: ChannelPlan) -> bool:
-    return plan.fmt == "s16" and plan.taps_natural is not None and -(-plan.ntaps // plan.decimation) <= MFMA_Q
+    return plan.fmt == "s16" and plan.taps_natural is not None
 
 
-@functools.lru_cache(maxsize=16)
-def _mfma_layout(ntaps: int, decimation: int):
-    """Index tables of the tap-fragment layout; they depend only on (L, D)."""
+@functools.lru_cache(maxsize=32)
+def _mfma_layout(ntaps: int, decimation: int, group: int):
+    """Index tables of the tap-fragment layout; they depend only on (L, D, q-group)."""
     L, D = ntaps, decimation
     ksteps = -(-2 * D // 32)
-    q = np.arange(1, MFMA_Q + 1, dtype=np.int64)[:, None]
+    q = np.arange(1, MFMA_Q + 1, dtype=np.int64)[:, None] + MFMA_Q * group
     rho = np.arange(D, dtype=np.int64)[None, :]
     k = q * D - 1 - rho
     ok = (k >= 0) & (k < L)
@@ -201,43 +239,58 @@ def plan_mfma(plan: ChannelPlan) -> MfmaPlan:
     """Quantise the (already NCO-rotated, scaled) taps to 16-bit fixed point and lay them out as
     the A operand of v_mfma_i32_32x32x32_i8.
 
-    Rows: row = comp*64 + (q-1), q = 1..64; columns kap = 2*rho + c over one data row of D frames:
+    Rows: row = comp*64 + (q-1) within a q-group of 64 tap rows; columns kap = 2*rho + c over one
+    data row of D frames:
         A[(re,q)][2rho] = Re g[qD-1-rho]   A[(re,q)][2rho+1] = -Im g[qD-1-rho]
         A[(im,q)][2rho] = Im g[qD-1-rho]   A[(im,q)][2rho+1] =  Re g[qD-1-rho]
-    T = rint(A/u), u = max|A|/32639; T = 256*q1 + q2 with both bytes signed.
+    T = rint(A/u), u = max|A|/32639 per group; T = 256*q1 + q2 with both bytes signed.
     Fragment order (verified on hardware): lane l holds row l&31, k = 16*(l>>5) + j.
+    Filters with ceil(L/D) > 64 get several q-groups, decimations whose fragments exceed LDS get
+    several k-step ranges; every (group, range) is one pass of the kernel.
     """
     if not mfma_supported(plan):
-        raise ValueError("MFMA channelizer needs an int16 capture and ceil(ntaps/decimation) <= 64")
+        raise ValueError("MFMA channelizer needs an int16 capture")
     g = plan.taps_natural
     D = plan.decimation
-    ksteps, kc, ok, flat = _mfma_layout(plan.ntaps, D)
-    kpad = 32 * ksteps
-    gk = g[kc]
-    gre = np.where(ok, gk.real, 0.0)
-    gim = np.where(ok, gk.imag, 0.0)
-    a = np.zeros((2 * MFMA_Q, kpad), dtype=np.float64)
-    a[:MFMA_Q, 0 : 2 * D : 2] = gre
-    a[:MFMA_Q, 1 : 2 * D : 2] = -gim
-    a[MFMA_Q:, 0 : 2 * D : 2] = gim
-    a[MFMA_Q:, 1 : 2 * D : 2] = gre
-    amax = float(np.abs(a).max())
-    unit = amax / 32639.0 if amax > 0 else 1.0
-    t = np.rint(a * (1.0 / unit)).astype(np.int32)
-    q2 = ((t + 128) & 255) - 128
-    q1 = (t - q2) >> 8
-    frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
-    frag[:, :, 0] = q1.reshape(-1)[flat]
-    frag[:, :, 1] = q2.reshape(-1)[flat]
-    return MfmaPlan(ksteps, frag, unit, 128.0 * float(t[:MFMA_Q].sum(dtype=np.int64)),
-                    128.0 * float(t[MFMA_Q:].sum(dtype=np.int64)), t)
+    n_groups = max(1, -(-(-(-plan.ntaps // D)) // MFMA_Q))
+    groups, passes = [], []
+    ksteps = -(-2 * D // 32)
+    n_chunks = -(-ksteps // MFMA_MAX_KSTEPS_PER_PASS)
+    bounds = [round(i * ksteps / n_chunks) for i in range(n_chunks + 1)]
+    for gi in range(n_groups):
+        _, kc, ok, flat = _mfma_layout(plan.ntaps, D, gi)
+        kpad = 32 * ksteps
+        gk = g[kc]
+        gre = np.where(ok, gk.real, 0.0)
+        gim = np.where(ok, gk.imag, 0.0)
+        a = np.zeros((2 * MFMA_Q, kpad), dtype=np.float64)
+        a[:MFMA_Q, 0 : 2 * D : 2] = gre
+        a[:MFMA_Q, 1 : 2 * D : 2] = -gim
+        a[MFMA_Q:, 0 : 2 * D : 2] = gim
+        a[MFMA_Q:, 1 : 2 * D : 2] = gre
+        amax = float(np.abs(a).max())
+        unit = amax / 32639.0 if amax > 0 else 1.0
+        t = np.rint(a * (1.0 / unit)).astype(np.int32)
+        q2 = ((t + 128) & 255) - 128
+        q1 = (t - q2) >> 8
+        frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
+        frag[:, :, 0] = q1.reshape(-1)[flat]
+        frag[:, :, 1] = q2.reshape(-1)[flat]
+        groups.append(MfmaGroup(frag, unit, t))
+        for ci in range(n_chunks):
+            k0, k1 = bounds[ci], bounds[ci + 1]
+            sl = t[:, 32 * k0 : 32 * k1]
+            passes.append(MfmaPass(gi, k0, k1 - k0, 128.0 * float(sl[:MFMA_Q].sum(dtype=np.int64)),
+                                   128.0 * float(sl[MFMA_Q:].sum(dtype=np.int64))))
+    return MfmaPlan(ksteps, groups, passes)
 
 
-def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decimation: int, ksteps: int):
+def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decimation: int, ksteps: int,
+                  n_groups: int = 1):
     """(m_a, m_b): the sub-range of outputs [m_first, m_first+n_out) whose whole MFMA read range
-    (columns m-64 .. m+29, each 16*ksteps frames from frame b*D+1) lies inside this block's frames."""
+    (columns m-64*n_groups .. m+29, each 16*ksteps frames from frame b*D+1) lies inside this block's frames."""
     d = decimation
-    m_a = max(m_first, MFMA_Q + -(-max(consumed - 1, 0) // d))
+    m_a = max(m_first, MFMA_Q * n_groups + -(-max(consumed - 1, 0) // d))
     m_b = min(m_first + n_out, (n_frames + consumed - 16 * ksteps) // d - 30)
     return (m_a, m_b) if m_b > m_a else (m_first, m_first)
 

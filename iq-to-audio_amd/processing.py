@@ -162,27 +162,27 @@ class _ChannelKernel:
             out_scale_re=float(np.real(plan.out_scale)), out_scale_im=float(np.imag(plan.out_scale)),
         )
         self.mfma = None  # planned lazily, the first time a block is long enough to use it
-        self._mfma_range = 0
-        if self.use_mfma and P.mfma_supported(plan):
-            afrag_bytes = int(N.lib().iqa_mfma_afrag_bytes(plan.decimation))
-            # one 8-wave block per CU owns all 160 KiB of LDS: tap fragments + 16 B per output of accumulators
-            rng = ((160 * 1024 - afrag_bytes) // 16 - 160) // 32 * 32
-            if rng >= 512:
-                self._mfma_range = min(rng, 6144)
+        self._mfma_ok = bool(self.use_mfma and P.mfma_supported(plan))
 
     def _ensure_mfma(self):
         if self.mfma is None:
             mp = P.plan_mfma(self.plan)
             self.mfma = mp
-            self.afrag_dev = D.from_numpy(mp.afrag.reshape(-1).view(np.uint8))
-            self.mfma_params = N.MfmaParams(outputs_per_block=self._mfma_range, reserved=0, unit=mp.unit,
-                                            c_re=mp.c_re, c_im=mp.c_im)
+            self.afrag_dev = [D.from_numpy(g.afrag.reshape(-1).view(np.uint8)) for g in mp.groups]
+            self.mfma_params = []
+            for ps in mp.passes:
+                # one 8-wave block per CU owns all 160 KiB of LDS: this pass's tap fragments + 16 B per output
+                rng = ((160 * 1024 - ps.k_count * P.MFMA_KSTEP_BYTES) // 16 - 160) // 32 * 32
+                self.mfma_params.append(N.MfmaParams(
+                    outputs_per_block=min(rng, 6144), reserved=0, unit=mp.groups[ps.group].unit, c_re=ps.c_re,
+                    c_im=ps.c_im, debug_stamps=None, q_group=ps.group, k_first=ps.k_first, k_count=ps.k_count,
+                    finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
 
-    def _block_outputs(self, n_out: int) -> int:
+    @staticmethod
+    def _block_outputs(n_out: int, rmax: int) -> int:
         """Outputs per block for a launch of ``n_out`` outputs: as large as LDS allows, but chosen so that the
         number of blocks is a multiple of the 256 CUs (one block per CU, no ragged last round)."""
-        rmax = self._mfma_range
         rounds = max(1, -(-n_out // (256 * rmax)))
         per = -(-n_out // (256 * rounds))
         return int(min(rmax, max(512, -(-per // 32) * 32)))
@@ -198,19 +198,30 @@ class _ChannelKernel:
         if out_dev is None:
             out_dev = D.empty(n_out, "complex64")
         self.last_kernel = "k_channelize_v1"
-        if self._mfma_range and n_out >= self.mfma_min_outputs:
-            ksteps = -(-2 * self.plan.decimation // 32)
-            m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, self.plan.decimation, ksteps)
+        if self._mfma_ok and n_out >= self.mfma_min_outputs:
+            d = self.plan.decimation
+            ksteps = -(-2 * d // 32)
+            n_groups = max(1, -(-(-(-self.plan.ntaps // d)) // P.MFMA_Q))
+            m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, d, ksteps, n_groups)
             if m_b - m_a >= self.mfma_min_outputs:
-                self._ensure_mfma()
+                mp = self._ensure_mfma()
+                n_int = m_b - m_a
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
                 self.last_kernel = "k_channelize_mfma_s16"
-                self.mfma_params.outputs_per_block = self._block_outputs(m_b - m_a)
+                partial = D.empty(2 * n_int, "float64") if len(mp.passes) > 1 else None
                 if events:
                     events[0].record()
-                N.call("iqa_channelize_mfma", byref(self.params), byref(self.mfma_params), N.ptr(self.afrag_dev),
-                       N.ptr(raw_dev), c_int64(n_frames), c_int64(consumed), c_int64(m_a), c_int64(m_b - m_a),
-                       N.ptr(out_dev[m_a - m_first :]), N.stream_ptr())
+                for i, (ps, prm) in enumerate(zip(mp.passes, self.mfma_params)):
+                    last = i == len(mp.passes) - 1
+                    rmax = min(6144, ((160 * 1024 - ps.k_count * P.MFMA_KSTEP_BYTES) // 16 - 160) // 32 * 32)
+                    prm.outputs_per_block = self._block_outputs(n_int, rmax)
+                    prm.finalize = int(last)
+                    prm.partial_in_dev = partial.data_ptr() if (partial is not None and i > 0) else None
+                    prm.partial_out_dev = partial.data_ptr() if (partial is not None and not last) else None
+                    afrag = self.afrag_dev[ps.group][ps.k_first * P.MFMA_KSTEP_BYTES :]
+                    N.call("iqa_channelize_mfma", byref(self.params), byref(prm), N.ptr(afrag), N.ptr(raw_dev),
+                           c_int64(n_frames), c_int64(consumed), c_int64(m_a), c_int64(n_int),
+                           N.ptr(out_dev[m_a - m_first :]), N.stream_ptr())
                 if events:
                     events[1].record()
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_b, m_first + n_out - m_b, out_dev[m_b - m_first :])
@@ -315,7 +326,7 @@ class Channelizer:
 
     def plan_ahead(self) -> None:
         """Do the host-side MFMA planning and tap upload now (otherwise done lazily by the first long block)."""
-        if self._kernel._mfma_range:
+        if self._kernel._mfma_ok:
             self._kernel._ensure_mfma()
 
     def outputs_for(self, n_frames: int) -> tuple[int, int]:
@@ -556,6 +567,54 @@ def _encode_iq_raw(samples: np.ndarray, codec: str) -> bytes:
     raise ValueError(f"Unsupported codec {codec}")
 
 
+class _BlockStager:
+    """Capture blocks: memory-mapped file -> one of two pinned host buffers (filled by a helper thread,
+    overlapping the previous block's GPU work) -> device tensor by asynchronous H2D copy.
+    Replaces the reference's ffmpeg decode pipe + ``IQReader.read_block`` (processing.py:238-266): the
+    capture's own sample format goes to the GPU untouched."""
+
+    def __init__(self, frames: np.ndarray, dtype: str, max_frames: int):
+        torch = D.torch_mod()
+        self.frames = frames
+        self.dtype = getattr(torch, dtype)
+        self.bufs = [torch.empty(2 * max_frames, dtype=self.dtype).pin_memory() for _ in range(2)]
+        self.events = [None, None]
+        self.pending = None  # (thread, slot, lo, hi)
+        self.slot = 0
+
+    def _fill(self, slot: int, lo: int, hi: int) -> None:
+        np.copyto(self.bufs[slot].numpy()[: 2 * (hi - lo)], self.frames[2 * lo : 2 * hi])
+
+    def prefetch(self, lo: int, hi: int) -> None:
+        import threading
+
+        slot = self.slot ^ 1
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()  # the previous H2D out of this buffer must be done
+        th = threading.Thread(target=self._fill, args=(slot, lo, hi), name="iq-stager", daemon=True)
+        th.start()
+        self.pending = (th, slot, lo, hi)
+
+    def fetch(self, lo: int, hi: int):
+        torch = D.torch_mod()
+        if self.pending is not None and self.pending[2:] == (lo, hi):
+            th, slot = self.pending[0], self.pending[1]
+            th.join()
+        else:
+            slot = self.slot ^ 1
+            if self.events[slot] is not None:
+                self.events[slot].synchronize()
+            self._fill(slot, lo, hi)
+        self.pending = None
+        self.slot = slot
+        dev = torch.empty(2 * (hi - lo), dtype=self.dtype, device=D.device())
+        dev.copy_(self.bufs[slot][: 2 * (hi - lo)], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        return dev
+
+
 class ProcessingPipeline:
     """``ProcessingPipeline(config).run(progress_sink) -> ProcessingResult``, ``.cancel()``
     (reference processing.py:682-1213).
@@ -686,9 +745,11 @@ class ProcessingPipeline:
             torch = D.torch_mod()
             np_dt = {"s16": "int16", "u8": "uint8", "f32": "float32"}[info.fmt]
 
+            block = max(1, self.block_frames_target // chunk) * chunk
+            stager = _BlockStager(frames, np_dt, min(block, total))
+
             def upload(lo: int, hi: int):
-                host = np.ascontiguousarray(frames[2 * lo : 2 * hi])
-                return torch.from_numpy(host).to(D.device(), non_blocking=False)
+                return stager.fetch(lo, hi)
 
             warm = upload(0, min(chunk, total))
             _check_cancel("warm-up")
@@ -714,13 +775,14 @@ class ProcessingPipeline:
             n_dec_total = -(-total // decimation)
             z_all = D.empty(n_dec_total, "complex64") if (pass_through or cfg.dump_iq_path) else None
             audio_all = None if pass_through else D.empty(n_dec_total, "float32")
-            block = max(1, self.block_frames_target // chunk) * chunk
             done = 0
             pos_dec = 0
             while done < total:
                 _check_cancel(f"block at frame {done}")
                 hi = min(done + block, total)
                 raw = warm if (done == 0 and hi <= warm.numel() // 2) else upload(done, hi)
+                if hi < total:
+                    stager.prefetch(hi, min(hi + block, total))  # disk -> pinned memory while the GPU works
                 n = hi - done
                 tracker.advance("ingest", float(n))
                 tracker.status(f"channel @ {done}")

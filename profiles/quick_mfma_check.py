@@ -16,7 +16,7 @@ z = D.empty(-(-n_total // d), "complex64")
 import os
 for dbg in [int(x) for x in os.environ.get('DBG', '0,1').split(',')]:
     ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
-    ch.plan_ahead(); ch._kernel.mfma_params.reserved = dbg
+    ch.plan_ahead(); ch._kernel.mfma_params[0].reserved = dbg
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for it in range(6):
@@ -29,10 +29,10 @@ ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimati
 ch.plan_ahead()
 nblk = -(-(n_total // d) // 512) + 2
 st = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device="cuda")
-ch._kernel.mfma_params.reserved = 2
-ch._kernel.mfma_params.debug_stamps = st.data_ptr()
+ch._kernel.mfma_params[0].reserved = 2
+ch._kernel.mfma_params[0].debug_stamps = st.data_ptr()
 ch.process(raw, out_dev=z); torch.cuda.synchronize()
 s = st.cpu().numpy().reshape(-1, 8)
 s = s[s[:, 4] > 0]
-print("outputs/block:", ch._kernel.mfma_params.outputs_per_block); print("waves:", len(s), "median cycles: prologue %d, loop %d (scatter %d), tail %d, tiles/wave %d" % tuple(np.median(s[:, i]) for i in range(5)))
+print("outputs/block:", ch._kernel.mfma_params[0].outputs_per_block); print("waves:", len(s), "median cycles: prologue %d, loop %d (scatter %d), tail %d, tiles/wave %d" % tuple(np.median(s[:, i]) for i in range(5)))
 print("per tile: loop %.0f cycles, of which scatter %.0f; ideal MFMA per tile %d" % (np.median(s[:, 1] / s[:, 4]), np.median(s[:, 2] / s[:, 4]), 7 * 12 * 32))

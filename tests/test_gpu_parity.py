@@ -476,7 +476,12 @@ def test_pipeline_cancel_removes_partial_output(A, tmp_path):
 # ---- int8-MFMA form of the channelizer -----------------------------------------------------------
 
 
-@pytest.mark.parametrize("fs,d,bw,n", [(2.5e6, 26, 12500.0, 4_000_000), (10e6, 104, 12500.0, 6_000_000)])
+@pytest.mark.parametrize("fs,d,bw,n", [
+    (2.5e6, 26, 12500.0, 4_000_000),      # C1 shape: 1601 taps, one pass
+    (10e6, 104, 12500.0, 6_000_000),      # C2 shape: 6401 taps, one pass
+    (20e6, 208, 2800.0, 12_000_000),      # C3 narrow channel: 32769 taps = 158 tap rows -> 3 q-groups
+    (50e6, 521, 12500.0, 16_000_000),     # C5 shape: 32001 taps, 33 k steps -> 3 k-step ranges
+])
 def test_mfma_channelizer_vs_valu_and_oracle(A, fs, d, bw, n):
     """The matrix-core path (exact int32 accumulation of int8 pieces, 16-bit fixed-point taps) against the
     float32 VALU kernel and the oracle: error is the documented tap-quantisation floor (~2e-6 of full
@@ -518,3 +523,52 @@ def test_mfma_channelizer_vs_valu_and_oracle(A, fs, d, bw, n):
     assert rms(valu[:k] - want) < 2e-7
     assert rms(mfma[:k] - want) < 4e-6 and np.abs(mfma[:k] - want).max() < 2e-5
     assert rms(mfma - valu) < 4e-6 and np.abs(mfma - valu).max() < 2e-5
+
+
+@pytest.mark.parametrize("mode,fmt", [("nfm", "s16"), ("am", "s16"), ("usb", "s16"), ("nfm", "u8"), ("nfm", "f32")])
+def test_pipeline_multi_block_streaming(A, tmp_path, mode, fmt):
+    """Several device blocks (history, decimator phase, IIR states and AGC restarts carried across blocks,
+    pinned double-buffered staging) on raw captures of every sample format, against the oracle."""
+    from iq_to_audio_amd.benchmark import synthetic_iq_s16
+
+    fs, f_off, secs = 2.5e6, 25e3, 2.2
+    s16 = synthetic_iq_s16(fs, secs, f_off).reshape(-1)
+    if fmt == "s16":
+        raw, suffix = s16, ".cs16"
+    elif fmt == "u8":
+        raw, suffix = ((s16.astype(np.int32) >> 8) + 128).astype(np.uint8), ".cu8"
+    else:
+        raw, suffix = (s16.astype(np.float32) / np.float32(32768.0)), ".cf32"
+    path = tmp_path / f"cap_400000000Hz{suffix}"
+    path.write_bytes(raw.tobytes())
+    agc = mode != "usb"  # keep the SSB case on the well-conditioned (AGC off) path
+    cfg = A.ProcessingConfig(in_path=path, target_freq=400_025_000.0, demod_mode=mode, agc_enabled=agc,
+                             input_sample_rate=fs, output_path=tmp_path / "o.wav")
+    pipe = A.ProcessingPipeline(cfg)
+    pipe.block_frames_target = 2 * 1_048_576  # 3 blocks of 2 chunks for 5.5 M frames
+    pipe.keep_channel_audio = True
+    res = pipe.run()
+    want = O.run_chain(raw, sample_rate=fs, freq_offset=f_off, demod_mode=mode, agc_enabled=agc, fmt=fmt, keep_decimated=False)
+    got = pipe.audio_fs_channel.cpu().numpy()
+    assert got.size == want.audio.size and res.mix_sign == want.mix_sign
+    assert rms(got - want.audio) < 2e-5
+    assert abs(res.audio_peak - want.audio_peak) < 1e-4 * max(1.0, want.audio_peak)
+    assert len(pipe.chunk_rms_dbfs) == len(want.rms_dbfs)
+    np.testing.assert_allclose(pipe.chunk_rms_dbfs, want.rms_dbfs, atol=1e-2)
+
+
+def test_run_benchmark_contract(A, caplog):
+    """reference tests/test_benchmark.py:56-70: run_benchmark returns 0 and logs the 'x realtime' line."""
+    import logging
+
+    from iq_to_audio_amd.benchmark import run_benchmark
+
+    with caplog.at_level(logging.INFO):
+        rc = run_benchmark(seconds=0.5, sample_rate=2.5e6, freq_offset=25e3, center_freq=None, target_freq=None,
+                           base_kwargs={"demod_mode": "nfm", "bandwidth": 12_500.0})
+    assert rc == 0
+    assert any("Benchmark processed" in r.message and "realtime" in r.message for r in caplog.records)
+    with pytest.raises(ValueError):
+        run_benchmark(seconds=0.0, sample_rate=2.5e6, freq_offset=25e3, center_freq=None, target_freq=None, base_kwargs=None)
+    with pytest.raises(ValueError):
+        run_benchmark(seconds=1.0, sample_rate=2.5e6, freq_offset=2e6, center_freq=None, target_freq=None, base_kwargs=None)
