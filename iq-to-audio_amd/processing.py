@@ -148,6 +148,10 @@ class _ChannelKernel:
 
     #: set to False to force the float32 VALU kernel everywhere (tests compare the two)
     use_mfma = True
+    #: data path of the MFMA kernel: "plain" (per-lane row loads into VGPRs), "staged8" (8 waves, LDS-DMA ring of 4),
+    #: "staged12" (12 waves = three per SIMD, ring of 3, tap fragments read just in time)
+    mfma_variant = "plain"
+    _VARIANT = {"plain": (0, 0), "staged8": (4, 8 * 4 * 2048), "staged12": (4 | 8, 12 * 3 * 2048)}  # flags, LDS ring bytes
     mfma_min_outputs = 32768
 
     def __init__(self, plan: P.ChannelPlan):
@@ -172,12 +176,20 @@ class _ChannelKernel:
             self.mfma_params = []
             for ps in mp.passes:
                 # one 8-wave block per CU owns all 160 KiB of LDS: this pass's tap fragments + 16 B per output
-                rng = ((160 * 1024 - ps.k_count * P.MFMA_KSTEP_BYTES) // 16 - 160) // 32 * 32
+                variant = self.mfma_variant
+                if self._range_max(ps.k_count, variant) < 512:  # the staging ring does not fit LDS next to the taps
+                    variant = "plain"
+                rng = self._range_max(ps.k_count, variant)
+                self._pass_variant = getattr(self, "_pass_variant", []) + [variant]
                 self.mfma_params.append(N.MfmaParams(
-                    outputs_per_block=min(rng, 6144), reserved=0, unit=mp.groups[ps.group].unit, c_re=ps.c_re,
+                    outputs_per_block=rng, reserved=self._VARIANT[variant][0], unit=mp.groups[ps.group].unit, c_re=ps.c_re,
                     c_im=ps.c_im, debug_stamps=None, q_group=ps.group, k_first=ps.k_first, k_count=ps.k_count,
                     finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
+
+    def _range_max(self, k_count: int, variant: str) -> int:
+        lds = 160 * 1024 - k_count * P.MFMA_KSTEP_BYTES - self._VARIANT[variant][1]
+        return int(min(6144, (lds // 16 - 160) // 32 * 32))
 
     @staticmethod
     def _block_outputs(n_out: int, rmax: int) -> int:
@@ -213,8 +225,7 @@ class _ChannelKernel:
                     events[0].record()
                 for i, (ps, prm) in enumerate(zip(mp.passes, self.mfma_params)):
                     last = i == len(mp.passes) - 1
-                    rmax = min(6144, ((160 * 1024 - ps.k_count * P.MFMA_KSTEP_BYTES) // 16 - 160) // 32 * 32)
-                    prm.outputs_per_block = self._block_outputs(n_int, rmax)
+                    prm.outputs_per_block = self._block_outputs(n_int, self._range_max(ps.k_count, self._pass_variant[i]))
                     prm.finalize = int(last)
                     prm.partial_in_dev = partial.data_ptr() if (partial is not None and i > 0) else None
                     prm.partial_out_dev = partial.data_ptr() if (partial is not None and not last) else None

@@ -303,3 +303,27 @@ def test_reference_ssb_agc_is_ill_conditioned_on_the_benchmark_capture():
     without = np.sqrt(np.mean((audio(z, False) - audio(zp, False)) ** 2))
     assert with_agc > 1e-3  # three+ orders of magnitude above the perturbation
     assert without < 1e-6  # the linear path is perfectly well conditioned
+
+
+# ---- CLI shim (argument surface only; running it needs a GPU) ----------------------------------------
+
+
+def test_cli_argument_surface():
+    from iq_to_audio_amd import cli
+
+    p = cli.build_parser()
+    a = p.parse_args(["--in", "x.wav", "--ft", "100e6", "--ft", "101e6", "--demod", "usb", "--no-agc", "--iq-order", "qi_inv",
+                      "--mix-sign", "-1", "--preview", "5", "--input-format", "raw:cs16", "--input-sample-rate", "2.4e6"])
+    assert a.target_freqs == [100e6, 101e6] and a.demod == "usb" and a.agc_enabled is False and a.mix_sign == -1
+    assert (a.bandwidth, a.fs_ch, a.deemph_us, a.chunk_size, a.filter_block) == (12_500.0, 96_000.0, 300.0, 1_048_576, 65_536)
+    assert (a.benchmark_seconds, a.benchmark_sample_rate, a.benchmark_offset) == (5.0, 2_500_000.0, 25_000.0)
+    assert cli.parse_user_format("raw:cs16") == ("raw", "pcm_s16le") and cli.parse_user_format("f32") == (None, "pcm_f32le")
+    with pytest.raises(ValueError):
+        cli.parse_user_format("mp3")
+    for bad in (["--in", "x.wav", "--ft", "1e6", "--ft", "1e6"],  # duplicate within 0.5 Hz
+                ["--in", "x.wav"] + sum((["--ft", str(1e6 + i)] for i in range(6)), []),  # more than five targets
+                ["--ft", "1e6"],  # no input
+                ["--in", "x.wav", "--ft", "-5"]):  # positive_float
+        with pytest.raises(SystemExit) as exc:
+            cli.main(bad)
+        assert exc.value.code == 2
