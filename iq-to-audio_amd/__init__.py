@@ -17,6 +17,7 @@ from .processing import (  # noqa: F401
     Channelizer,
     ComplexOscillator,
     Decimator,
+    MultiChannelPipeline,
     OverlapSaveFIR,
     ProcessingCancelled,
     ProcessingConfig,

@@ -67,3 +67,34 @@ def run_benchmark(*, seconds: float, sample_rate: float, freq_offset: float, cen
     LOG.info("Benchmark processed %d IQ samples in %.3f s (%.2fx realtime).", n, elapsed,
              seconds / elapsed if elapsed > 0 else float("inf"))
     return 0
+
+
+def synthetic_multi_iq_s16(sample_rate: float, seconds: float, carriers, *, noise_std: float = 0.02, seed: int = 42,
+                           tone_hz: float = 1000.0) -> np.ndarray:
+    """Multi-carrier capture for BASELINE configs 3/5 (the reference has no multi-signal generator; this
+    recipe is build-defined): ``carriers`` = [(offset_hz, amplitude, mode), ...] with
+    mode 'nfm' (1 kHz tone, 3 kHz deviation), 'am' (depth 0.8), 'usb'/'lsb' (single tone 1 kHz above/below
+    the carrier position), plus the same AWGN / seed / clip / PCM16 rule as the single-tone generator."""
+    total = int(round(sample_rate * seconds))
+    if total <= 0:
+        raise ValueError("Benchmark duration is too short to generate samples.")
+    t = np.arange(total, dtype=np.float64) / sample_rate
+    x = np.zeros(total, dtype=np.complex128)
+    msg = np.sin(2.0 * math.pi * tone_hz * t)
+    for offset, amp, mode in carriers:
+        mode = mode.lower()
+        if mode in ("nfm", "fm"):
+            phase = 2.0 * math.pi * offset * t + (3000.0 / tone_hz) * (1.0 - np.cos(2.0 * math.pi * tone_hz * t))
+            x += amp * np.exp(1j * phase)
+        elif mode == "am":
+            x += amp * (1.0 + 0.8 * msg) / 1.8 * np.exp(2j * math.pi * offset * t)
+        elif mode in ("usb", "ssb"):
+            x += amp * np.exp(2j * math.pi * (offset + tone_hz) * t)
+        elif mode == "lsb":
+            x += amp * np.exp(2j * math.pi * (offset - tone_hz) * t)
+        else:
+            raise ValueError(f"unknown carrier mode {mode!r}")
+    noise = np.random.default_rng(seed).normal(scale=noise_std, size=(total, 2))
+    iq = np.column_stack((x.real + noise[:, 0], x.imag + noise[:, 1]))
+    iq = np.clip(iq.astype(np.float32), -0.999, 0.999)
+    return np.rint(iq.astype(np.float64) * 32767.0).astype(np.int16)

@@ -21,7 +21,7 @@ import sys
 from pathlib import Path
 
 from .benchmark import run_benchmark
-from .processing import ProcessingCancelled, ProcessingConfig, ProcessingPipeline
+from .processing import MultiChannelPipeline, ProcessingCancelled, ProcessingConfig, ProcessingPipeline
 
 LOG = logging.getLogger("iq_to_audio_amd")
 
@@ -133,25 +133,30 @@ def main(argv: list[str] | None = None) -> int:
             return base
         return base.with_name(f"{base.stem}_{int(round(freq))}{base.suffix}")
 
-    for index, freq in enumerate(frequencies or [0.0], start=1):
+    configs = []
+    for freq in frequencies or [0.0]:
         config = ProcessingConfig(in_path=args.input_path, target_freq=freq, output_path=annotate(args.output_path, freq),
                                   dump_iq_path=annotate(args.dump_iq, freq), **shared)
         if args.preview_seconds:
             config = dataclasses.replace(config, max_input_seconds=args.preview_seconds,
                                          output_path=_preview_output_path(config))
-        LOG.info("=== Processing target %.0f Hz (%d/%d) ===", freq, index, max(1, len(frequencies)))
-        try:
-            result = ProcessingPipeline(config).run(progress_sink=None)
-        except ProcessingCancelled:
-            LOG.info("Processing cancelled by user.")
-            return 0
-        except Exception as exc:  # noqa: BLE001
-            LOG.error("Processing failed for %.0f Hz: %s", freq, exc)
-            if args.verbose:
-                LOG.exception("Debug traceback")
-            return 1
-        LOG.info("decimation %d -> %.2f Hz, mixer sign %+d, audio peak %.4f", result.decimation, result.fs_channel,
-                 result.mix_sign, result.audio_peak)
+        configs.append(config)
+    LOG.info("=== Processing %d target(s) in one pass over %s ===", len(configs), args.input_path)
+    try:
+        # the reference loops whole pipelines over the targets (cli.py:683-710); here the capture is read once
+        results = MultiChannelPipeline(configs).run(progress_sink=None) if len(configs) > 1 else [
+            ProcessingPipeline(configs[0]).run(progress_sink=None)]
+    except ProcessingCancelled:
+        LOG.info("Processing cancelled by user.")
+        return 0
+    except Exception as exc:  # noqa: BLE001
+        LOG.error("Processing failed: %s", exc)
+        if args.verbose:
+            LOG.exception("Debug traceback")
+        return 1
+    for config, result in zip(configs, results):
+        LOG.info("%.0f Hz: decimation %d -> %.2f Hz, mixer sign %+d, audio peak %.4f", config.target_freq,
+                 result.decimation, result.fs_channel, result.mix_sign, result.audio_peak)
     return 0
 
 

@@ -650,6 +650,8 @@ class ProcessingPipeline:
 
     def cancel(self) -> None:
         self._cancelled = True
+        if getattr(self, "_multi", None) is not None:
+            self._multi.cancel()
 
     def _is_pass_through_mode(self) -> bool:
         return (self.config.demod_mode or "").lower() in {"none", "pass", "iq"}
@@ -671,9 +673,143 @@ class ProcessingPipeline:
         return self.config.in_path.with_name(f"audio_{ft}_48k.wav")
 
     def run(self, progress_sink: ProgressSink | None = None) -> ProcessingResult:
-        cfg = self.config
+        """One target frequency: a :class:`MultiChannelPipeline` with a single channel."""
+        multi = MultiChannelPipeline([self.config], _owner=self)
+        self._multi = multi
+        if self._cancelled:
+            multi.cancel()
+        return multi.run(progress_sink)[0]
+
+
+class _Target:
+    """Per-target streaming state of a run: channelizer, demodulator, output buffers."""
+
+    def __init__(self, cfg: ProcessingConfig, owner, *, info, sample_rate, center_freq, decimation, fs_channel, total):
+        self.cfg, self.owner, self.info = cfg, owner, info
+        self.sample_rate, self.decimation, self.fs_channel, self.total = sample_rate, decimation, fs_channel, total
+        self.center_freq = center_freq
+        self.target_freq = cfg.target_freq if cfg.target_freq > 0 else center_freq
+        self.freq_offset = self.target_freq - center_freq
+        self.pass_through = (cfg.demod_mode or "").lower() in {"none", "pass", "iq"}
+        self.taps = design_channel_filter(sample_rate, cfg.bandwidth, decimation)
+        LOG.info("Designed FIR channel filter with %d taps.", len(self.taps))
+        if cfg.filter_block <= 0:
+            raise ValueError("block_size must be positive")
+        self.demod = None if self.pass_through else ChannelDemod(cfg.demod_mode, fs_channel, deemph_us=cfg.deemph_us,
+                                                                 agc_enabled=cfg.agc_enabled)
+        if cfg.iq_order not in N.ORDER:
+            raise ValueError(f"Unsupported iq_order '{cfg.iq_order}'")
+        self.chan = None
+        self.sign_probe = None
+        self.mix_sign = 1
+        self.pos_dec = 0
+        self.peak = 0.0
+        self.output_path = cfg.output_path if cfg.output_path else owner._default_output_path(info)
+
+    def _channelizer(self, sign: int) -> Channelizer:
+        return Channelizer(self.taps, sample_rate=self.sample_rate, freq_offset=self.freq_offset, mix_sign=sign,
+                           decimation=self.decimation, fmt=self.info.fmt, iq_order=self.cfg.iq_order)
+
+    def begin(self, warm) -> None:
+        """Launch the mixer-sign probes (asynchronously) and plan the channelizer for the likely sign meanwhile."""
+        if self.cfg.mix_sign_override in (1, -1):
+            self.mix_sign = self.cfg.mix_sign_override
+            self.chan = self._channelizer(self.mix_sign)
+        else:
+            self.sign_probe = MixSignProbe(warm, self.sample_rate, self.freq_offset, self.taps, self.decimation,
+                                           fmt=self.info.fmt, iq_order=self.cfg.iq_order)
+            self.chan = self._channelizer(1)
+        self.chan.plan_ahead()
+
+    def settle(self) -> None:
+        if self.sign_probe is not None:
+            self.mix_sign = self.sign_probe.result()
+            self.sign_probe = None
+            if self.mix_sign != 1:
+                self.chan = self._channelizer(self.mix_sign)
+        LOG.info("Selected mixer sign %d based on warm-up snippet.", self.mix_sign)
+        n_dec_total = -(-self.total // self.decimation)
+        self.z_all = D.empty(n_dec_total, "complex64") if (self.pass_through or self.cfg.dump_iq_path) else None
+        self.audio_all = None if self.pass_through else D.empty(n_dec_total, "float32")
+
+    def process(self, raw, done: int, n: int, chunk: int, tracker) -> None:
+        _, n_out = self.chan.outputs_for(n)
+        starts = None
+        if self.demod is not None and n_out:
+            starts = P.chunk_output_starts(chunk, self.decimation, done, n)
+            self.demod.prepare(n_out, starts)
+        z = self.chan.process(raw)
+        tracker.advance("channel", float(n_out))
+        if self.z_all is not None and n_out:
+            self.z_all[self.pos_dec : self.pos_dec + n_out] = z
+            if self.cfg.dump_iq_path:
+                tracker.advance("dump_iq", float(n_out))
+        if self.demod is not None and n_out:
+            self.demod.process(z, starts, self.audio_all[self.pos_dec : self.pos_dec + n_out])
+        tracker.advance("demod", float(n_out))
+        tracker.advance("encode", n_out / max(self.fs_channel, 1e-9) * 48_000.0)
+        self.pos_dec += n_out
+
+    def finish(self) -> None:
+        cfg, info = self.cfg, self.info
+        self.output_path.parent.mkdir(parents=True, exist_ok=True)
+        if cfg.dump_iq_path:
+            Path(cfg.dump_iq_path).write_bytes(self.z_all[: self.pos_dec].cpu().numpy().astype(np.complex64).tobytes())
+        if self.pass_through:
+            zs = self.z_all[: self.pos_dec].cpu().numpy()
+            self.peak = float(np.max(np.abs(zs))) if zs.size else 0.0
+            payload = _encode_iq_raw(zs, info.codec)
+            if info.container == "wav":
+                arr = np.frombuffer(payload, dtype=iqio.NP_DTYPE[info.fmt])
+                iqio.write_wav_iq(self.output_path, arr, int(round(self.fs_channel)), info.fmt)
+            else:
+                self.output_path.write_bytes(payload)
+            return
+        self.demod.decoder.finalize()
+        audio = self.audio_all[: self.pos_dec]
+        if self.owner.keep_channel_audio:
+            self.owner.audio_fs_channel = audio
+        rs = Resampler48k(self.fs_channel)
+        pcm = rs.to_pcm16(rs.process(audio)).cpu().numpy()
+        iqio.write_wav_pcm16(self.output_path, pcm, 48_000)
+        self.peak = self.demod.peak
+        self.owner.chunk_rms_dbfs = self.demod.chunk_rms_dbfs()
+        LOG.info("Audio peak level %.2f dBFS.", 20.0 * math.log10(max(self.peak, 1e-6)))
+
+
+class MultiChannelPipeline:
+    """Several target frequencies of ONE capture in a single pass over the file.
+
+    The reference CLI runs a whole pipeline per ``--ft`` target, re-decoding the input each time
+    (cli.py:683-710).  Here every block of the capture is staged and uploaded once and all channels
+    are extracted from the HBM-resident block (BASELINE configs 3/5); each channel keeps exactly the
+    per-target semantics of :class:`ProcessingPipeline` (own mixer-sign probe, taps, decoder, output).
+    ``configs`` must agree on the input file and its interpretation.
+    """
+
+    def __init__(self, configs: list, _owner=None):
+        if not configs:
+            raise ValueError("at least one ProcessingConfig is required")
+        if len(configs) > 5 and _owner is None:
+            LOG.debug("more than the reference CLI's five targets in one pass (%d)", len(configs))
+        first = configs[0]
+        for c in configs[1:]:
+            same = (c.in_path == first.in_path and c.input_format == first.input_format and c.input_container == first.input_container
+                    and c.input_sample_rate == first.input_sample_rate and c.chunk_size == first.chunk_size
+                    and c.max_input_seconds == first.max_input_seconds and c.center_freq == first.center_freq)
+            if not same:
+                raise ValueError("all targets of a multi-channel run must share the input file, format, rate and chunking")
+        self.configs = configs
+        self.owners = [_owner] if _owner is not None else [ProcessingPipeline(c) for c in configs]
+        self._cancelled = False
+
+    def cancel(self) -> None:
+        self._cancelled = True
+
+    def run(self, progress_sink: ProgressSink | None = None) -> list:
+        cfg = self.configs[0]
         tracker = ProgressTracker(progress_sink)
-        output_path: Path | None = None
+        targets: list[_Target] = []
 
         def _request_cancel() -> None:
             self._cancelled = True
@@ -681,7 +817,7 @@ class ProcessingPipeline:
             tracker.status("Cancelling…")
 
         def _check_cancel(stage: str = "") -> None:
-            if self._cancelled or tracker.cancelled:
+            if self._cancelled or tracker.cancelled or any(o._cancelled for o in self.owners):
                 self._cancelled = True
                 LOG.info("Processing cancelled during %s.", stage or "run")
                 raise ProcessingCancelled("Processing cancelled by user.")
@@ -696,14 +832,15 @@ class ProcessingPipeline:
         try:
             info = iqio.probe_capture(cfg.in_path, input_format=cfg.input_format, input_container=cfg.input_container,
                                       input_sample_rate=manual_rate)
-            cfg.input_container = cfg.input_container or info.container
-            cfg.input_format = cfg.input_format or info.codec
+            for c in self.configs:
+                c.input_container = c.input_container or info.container
+                c.input_format = c.input_format or info.codec
             if info.container == "raw" and manual_rate is None:
                 raise ValueError("Raw IQ inputs require --input-sample-rate (CLI) or a manual entry in the GUI.")
             if info.sample_rate is None or info.sample_rate <= 0:
                 raise RuntimeError("Unable to determine input sample rate automatically. Provide --input-sample-rate.")
             sample_rate = float(info.sample_rate)
-            probe = SampleRateProbe(header=None if manual_rate else sample_rate, wave=sample_rate)
+            rate_probe = SampleRateProbe(header=None if manual_rate else sample_rate, wave=sample_rate)
 
             preview_seconds = cfg.max_input_seconds
             if preview_seconds is not None and preview_seconds <= 0:
@@ -712,10 +849,11 @@ class ProcessingPipeline:
             if preview_seconds is not None:
                 total = min(total, max(1, int(math.floor(preview_seconds * sample_rate))))
 
-            if cfg.target_freq <= 0 and not cfg.probe_only:
-                raise ValueError("Target frequency must be positive. Provide --ft or use --interactive.")
-            if cfg.bandwidth <= 0:
-                raise ValueError("Bandwidth must be positive.")
+            for c in self.configs:
+                if c.target_freq <= 0 and not c.probe_only:
+                    raise ValueError("Target frequency must be positive. Provide --ft or use --interactive.")
+                if c.bandwidth <= 0:
+                    raise ValueError("Bandwidth must be positive.")
             center_freq = cfg.center_freq
             if center_freq is None:
                 center_freq, source = iqio.center_frequency_from_filename(cfg.in_path)
@@ -723,128 +861,75 @@ class ProcessingPipeline:
                     raise ValueError(
                         "Center frequency not supplied and could not be determined from metadata or filename. "
                         "Use --fc to provide it explicitly.")
-                cfg.center_freq, cfg.center_freq_source = center_freq, source
-            target_freq = cfg.target_freq if cfg.target_freq > 0 else center_freq
-            freq_offset = target_freq - center_freq
-            decimation, fs_channel = P.choose_decimation(sample_rate, cfg.fs_ch_target)
-            chunk = self._effective_chunk_size(sample_rate)
-            pass_through = self._is_pass_through_mode()
-            LOG.info("Input sample rate %.2f Hz; centre %.0f Hz, target %.0f Hz, offset %.0f Hz; decimation %d -> %.2f Hz",
-                     sample_rate, center_freq, target_freq, freq_offset, decimation, fs_channel)
+                for c in self.configs:
+                    c.center_freq, c.center_freq_source = center_freq, source
+            chunk = tune_chunk_size(sample_rate, cfg.chunk_size)
+            for o in self.owners:
+                o._resolved_chunk_size = chunk
 
-            n_dec_est = total / max(decimation, 1)
-            phases = [PhaseState("ingest", "Ingest IQ", float(total)), PhaseState("channel", "Channelize", n_dec_est),
-                      PhaseState("demod", "Demodulate", n_dec_est),
-                      PhaseState("encode", "Encode Audio", total / sample_rate * 48_000.0)]
-            if cfg.dump_iq_path:
-                phases.insert(3, PhaseState("dump_iq", "Write IQ Dump", n_dec_est))
+            n_est = 0.0
+            for c, o in zip(self.configs, self.owners):
+                decimation, fs_channel = P.choose_decimation(sample_rate, c.fs_ch_target)
+                LOG.info("Input sample rate %.2f Hz; centre %.0f Hz, target %.0f Hz; decimation %d -> %.2f Hz",
+                         sample_rate, center_freq, c.target_freq, decimation, fs_channel)
+                n_est += total / max(decimation, 1)
+            phases = [PhaseState("ingest", "Ingest IQ", float(total)), PhaseState("channel", "Channelize", n_est),
+                      PhaseState("demod", "Demodulate", n_est),
+                      PhaseState("encode", "Encode Audio", len(self.configs) * total / sample_rate * 48_000.0)]
+            if any(c.dump_iq_path for c in self.configs):
+                phases.insert(3, PhaseState("dump_iq", "Write IQ Dump", n_est))
             tracker.start(phases)
             tracker.status("design filter")
             _check_cancel("initialization")
-            taps = design_channel_filter(sample_rate, cfg.bandwidth, decimation)
-            LOG.info("Designed FIR channel filter with %d taps.", len(taps))
-            if cfg.filter_block <= 0:
-                raise ValueError("block_size must be positive")
-            if not pass_through:
-                demod = ChannelDemod(cfg.demod_mode, fs_channel, deemph_us=cfg.deemph_us, agc_enabled=cfg.agc_enabled)
-            if cfg.iq_order not in N.ORDER:
-                raise ValueError(f"Unsupported iq_order '{cfg.iq_order}'")
+            for c, o in zip(self.configs, self.owners):
+                decimation, fs_channel = P.choose_decimation(sample_rate, c.fs_ch_target)
+                targets.append(_Target(c, o, info=info, sample_rate=sample_rate, center_freq=center_freq,
+                                       decimation=decimation, fs_channel=fs_channel, total=total))
             if total == 0:
                 raise RuntimeError("Input stream produced no samples.")
 
             frames = iqio.map_frames(info)
-            torch = D.torch_mod()
             np_dt = {"s16": "int16", "u8": "uint8", "f32": "float32"}[info.fmt]
-
-            block = max(1, self.block_frames_target // chunk) * chunk
+            block = max(1, self.owners[0].block_frames_target // chunk) * chunk
             stager = _BlockStager(frames, np_dt, min(block, total))
-
-            def upload(lo: int, hi: int):
-                return stager.fetch(lo, hi)
-
-            warm = upload(0, min(chunk, total))
+            warm = stager.fetch(0, min(chunk, total))
             _check_cancel("warm-up")
-            chan = None
-            if cfg.mix_sign_override in (1, -1):
-                mix_sign = cfg.mix_sign_override
-            else:
-                # probes run on the GPU while the host plans the channelizer for the likely sign
-                probe = MixSignProbe(warm, sample_rate, freq_offset, taps, decimation, fmt=info.fmt, iq_order=cfg.iq_order)
-                chan = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=1,
-                                   decimation=decimation, fmt=info.fmt, iq_order=cfg.iq_order)
-                chan.plan_ahead()
-                mix_sign = probe.result()
-            LOG.info("Selected mixer sign %d based on warm-up snippet.", mix_sign)
-            output_path = cfg.output_path if cfg.output_path else self._default_output_path(info)
+            for t in targets:  # all probes are enqueued before the first read-back
+                t.begin(warm)
+            for t in targets:
+                t.settle()
             if cfg.probe_only:
                 tracker.advance("ingest", float(warm.numel() // 2))
-                return ProcessingResult(probe, center_freq, target_freq, freq_offset, decimation, fs_channel, mix_sign, 0.0)
+                return [ProcessingResult(rate_probe, center_freq, t.target_freq, t.freq_offset, t.decimation, t.fs_channel,
+                                         t.mix_sign, 0.0) for t in targets]
 
-            if chan is None or mix_sign != 1:
-                chan = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
-                                   decimation=decimation, fmt=info.fmt, iq_order=cfg.iq_order)
-            n_dec_total = -(-total // decimation)
-            z_all = D.empty(n_dec_total, "complex64") if (pass_through or cfg.dump_iq_path) else None
-            audio_all = None if pass_through else D.empty(n_dec_total, "float32")
             done = 0
-            pos_dec = 0
             while done < total:
                 _check_cancel(f"block at frame {done}")
                 hi = min(done + block, total)
-                raw = warm if (done == 0 and hi <= warm.numel() // 2) else upload(done, hi)
+                raw = warm if (done == 0 and hi <= warm.numel() // 2) else stager.fetch(done, hi)
                 if hi < total:
                     stager.prefetch(hi, min(hi + block, total))  # disk -> pinned memory while the GPU works
                 n = hi - done
                 tracker.advance("ingest", float(n))
                 tracker.status(f"channel @ {done}")
-                m_first, n_out = chan.outputs_for(n)
-                if not pass_through and n_out:
-                    starts = P.chunk_output_starts(chunk, decimation, done, n)
-                    demod.prepare(n_out, starts)
-                z = chan.process(raw)
-                tracker.advance("channel", float(n_out))
-                if z_all is not None and n_out:
-                    z_all[pos_dec : pos_dec + n_out] = z
-                    if cfg.dump_iq_path:
-                        tracker.advance("dump_iq", float(n_out))
-                if not pass_through and n_out:
-                    demod.process(z, starts, audio_all[pos_dec : pos_dec + n_out])
-                tracker.advance("demod", float(n_out))
+                for t in targets:
+                    t.process(raw, done, n, chunk, tracker)
                 _check_cancel("encode")
-                tracker.advance("encode", n_out / max(fs_channel, 1e-9) * 48_000.0)
-                pos_dec += n_out
                 done = hi
 
             tracker.status("flush outputs")
-            output_path.parent.mkdir(parents=True, exist_ok=True)
-            if cfg.dump_iq_path:
-                Path(cfg.dump_iq_path).write_bytes(z_all[:pos_dec].cpu().numpy().astype(np.complex64).tobytes())
-            if pass_through:
-                zs = z_all[:pos_dec].cpu().numpy()
-                peak = float(np.max(np.abs(zs))) if zs.size else 0.0
-                payload = _encode_iq_raw(zs, info.codec)
-                if info.container == "wav":
-                    arr = np.frombuffer(payload, dtype=iqio.NP_DTYPE[info.fmt])
-                    iqio.write_wav_iq(output_path, arr, int(round(fs_channel)), info.fmt)
-                else:
-                    output_path.write_bytes(payload)
-            else:
-                demod.decoder.finalize()
-                audio = audio_all[:pos_dec]
-                if self.keep_channel_audio:
-                    self.audio_fs_channel = audio
-                rs = Resampler48k(fs_channel)
-                pcm = rs.to_pcm16(rs.process(audio)).cpu().numpy()
-                iqio.write_wav_pcm16(output_path, pcm, 48_000)
-                peak = demod.peak
-                self.chunk_rms_dbfs = demod.chunk_rms_dbfs()
-                LOG.info("Audio peak level %.2f dBFS.", 20.0 * math.log10(max(peak, 1e-6)))
+            for t in targets:
+                t.finish()
             tracker.status("Processing complete")
-            return ProcessingResult(probe, center_freq, target_freq, freq_offset, decimation, fs_channel, mix_sign, peak)
+            return [ProcessingResult(rate_probe, center_freq, t.target_freq, t.freq_offset, t.decimation, t.fs_channel,
+                                     t.mix_sign, t.peak) for t in targets]
         except ProcessingCancelled:
-            if not cfg.probe_only and output_path:
-                with contextlib.suppress(OSError):
-                    output_path.unlink(missing_ok=True)
+            if not cfg.probe_only:
+                paths = [t.output_path for t in targets] or [c.output_path for c in self.configs if c.output_path]
+                for pth in paths:
+                    with contextlib.suppress(OSError):
+                        pth.unlink(missing_ok=True)
             raise
         finally:
             tracker.close()

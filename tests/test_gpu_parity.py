@@ -597,3 +597,51 @@ def test_mfma_variants_are_bit_identical(A):
     finally:
         PR._ChannelKernel.mfma_variant, PR._ChannelKernel.mfma_min_outputs = old
     assert torch.equal(outs["plain"], outs["staged8"]) and torch.equal(outs["plain"], outs["staged12"])
+
+
+def test_multi_channel_single_pass_and_cli(A, tmp_path):
+    """BASELINE config 3 pattern: several --ft targets (mixed demodulators, bandwidths) extracted from ONE pass
+    over the capture; every channel must equal its own single-target oracle run, and the CLI shim must
+    produce one 48 kHz WAV per target."""
+    from iq_to_audio_amd import cli, iqio
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+
+    fs, secs, fc = 2.5e6, 1.3, 433.0e6
+    carriers = [(25e3, 0.14, "nfm"), (-150e3, 0.14, "am"), (400e3, 0.14, "usb"), (-610e3, 0.14, "nfm")]
+    raw = synthetic_multi_iq_s16(fs, secs, carriers)
+    wav = tmp_path / "multi_433000000Hz.wav"
+    iqio.write_wav_iq(wav, raw, int(fs), "s16")
+    specs = [("nfm", 12_500.0, True), ("am", 10_000.0, True), ("usb", 2_800.0, False), ("nfm", 12_500.0, True)]
+    cfgs = [A.ProcessingConfig(in_path=wav, target_freq=fc + off, bandwidth=bw, demod_mode=mode, agc_enabled=agc,
+                               output_path=tmp_path / f"ch{i}.wav")
+            for i, ((off, _, _), (mode, bw, agc)) in enumerate(zip(carriers, specs))]
+    multi = A.MultiChannelPipeline(cfgs)
+    for o in multi.owners:
+        o.keep_channel_audio = True
+        o.block_frames_target = 1_048_576  # several blocks
+    results = multi.run()
+    assert len(results) == 4
+    for (off, _, _), (mode, bw, agc), res, owner in zip(carriers, specs, results, multi.owners):
+        want = O.run_chain(raw, sample_rate=fs, freq_offset=off, bandwidth=bw, demod_mode=mode, agc_enabled=agc,
+                           keep_decimated=False)
+        got = owner.audio_fs_channel.cpu().numpy()
+        assert got.size == want.audio.size and res.mix_sign == want.mix_sign == 1
+        assert abs(res.freq_offset - off) < 1e-6
+        assert rms(got - want.audio) < 2e-5, (mode, off)
+        assert rms(want.audio) > 1e-3  # the channel really carries its signal
+    for i in range(4):
+        assert (tmp_path / f"ch{i}.wav").stat().st_size > 100_000
+    # mixed inputs are rejected
+    other = tmp_path / "other.wav"
+    iqio.write_wav_iq(other, raw[:1000], int(fs), "s16")
+    with pytest.raises(ValueError):
+        A.MultiChannelPipeline([cfgs[0], A.ProcessingConfig(in_path=other, target_freq=fc)])
+    # the CLI shim: three targets, explicit --out gets the _<freq> suffix (reference cli.py:523-527)
+    out = tmp_path / "cli" / "a.wav"
+    rc = cli.main(["--in", str(wav), "--ft", str(fc + 25e3), "--ft", str(fc - 150e3), "--ft", str(fc - 610e3),
+                   "--out", str(out)])
+    assert rc == 0
+    for f in (fc + 25e3, fc - 150e3, fc - 610e3):
+        pcm, rate = iqio.read_wav_pcm16_mono(out.with_name(f"a_{int(round(f))}.wav"))
+        assert rate == 48000 and pcm.size == -(-(-(-raw.shape[0] // 26)) * 24000 // 48077)
+    assert cli.main(["--in", str(tmp_path / "missing.wav"), "--ft", "1e6", "--fc", "1e6"]) == 1
