@@ -14,7 +14,7 @@ seed-42 generator, tiled to 60 s in HBM -- SURVEY.md section 8(d)).
 
 N > 1 (launched by torch.distributed.run): every rank processes its own independent capture
 (BASELINE config 4 pattern, seeds 42+rank), no data-path collective, only the finished 48 kHz
-audio is gathered to rank 0 over RCCL.  scaling = "weak".
+PCM16 audio is gathered to rank 0 over RCCL (asynchronously, overlapping the next step).  scaling = "weak".
 
 Prints ONE JSON line on rank 0.
 """
@@ -92,7 +92,10 @@ def main() -> None:
     rs = Resampler48k(fs_ch)
     n48 = rs.plan.n_out(n_dec)
     pcm_host = torch.empty(n48, dtype=torch.int16).pin_memory()
-    gathered = [torch.empty(n48, dtype=torch.float32, device=D.device()) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # finished 48 kHz PCM16 audio of every capture is gathered on rank 0 (as bytes: RCCL has no int16 type)
+    gathered = [torch.empty(2 * n48, dtype=torch.uint8, device=D.device()) for _ in range(world)] if (world > 1 and rank == 0) else None
+    io_stream = torch.cuda.Stream()  # audio egress (D2H, RCCL gather) overlaps the next step's kernels
+    pending = []
     ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
     z = D.empty(n_dec, "complex64")
@@ -117,12 +120,21 @@ def main() -> None:
         dem.process(z, starts, audio)
         y48 = rs.process(audio)
         pcm = rs.to_pcm16(y48)
-        pcm_host.copy_(pcm, non_blocking=True)
-        if world > 1:
-            dist.gather(y48, gathered, dst=0)
+        done = torch.cuda.Event()
+        done.record()
+        io_stream.wait_event(done)
+        with torch.cuda.stream(io_stream):
+            pcm.record_stream(io_stream)
+            pcm_host.copy_(pcm, non_blocking=True)
+            if world > 1:
+                while pending:
+                    pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
+                pending.append(dist.gather(pcm.view(torch.uint8), gathered, dst=0, async_op=True))
         return sign, dem, y48
 
     def fence():
+        while pending:
+            pending.pop().wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -132,6 +144,11 @@ def main() -> None:
         if i == args.warmup - 2:
             fence()  # one untimed step runs right after a fence, exactly like the first timed step will
     fence()
+    stats0 = torch.cuda.memory_stats()
+    import gc
+
+    gc.collect()
+    gc.disable()  # a generation-2 collection in the middle of a 1.3 ms step shows up as a 10-50 ms stall
     t0 = time.perf_counter()
     marks = []
     for i in range(args.steps):
@@ -139,8 +156,11 @@ def main() -> None:
         marks.append(time.perf_counter() - t0)
     fence()
     if os.environ.get("IQA_BENCH_DEBUG"):
+        stats1 = torch.cuda.memory_stats()
+        keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")
         print("host-side step completion times (ms):", [round(m * 1e3, 2) for m in marks],
-              "after fence:", round((time.perf_counter() - t0) * 1e3, 2), file=sys.stderr)
+              "after fence:", round((time.perf_counter() - t0) * 1e3, 2),
+              "allocator deltas:", {k: stats1.get(k, 0) - stats0.get(k, 0) for k in keys}, file=sys.stderr)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=D.device())

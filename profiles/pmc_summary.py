@@ -13,7 +13,7 @@ import sys
 from pathlib import Path
 
 out_dir, tag = Path(sys.argv[1]), sys.argv[2]
-KERNEL = sys.argv[3] if len(sys.argv) > 3 else "k_channelize"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "k_channelize_mfma"
 
 
 def find(sub, pattern):
