@@ -334,6 +334,7 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 // contiguous 16-float runs; the table is read once in total.
 constexpr int RS_WAVES = 4;
 constexpr int RS_MAX_NI = 12;  // rows up to 192 taps
+template <int NI>  // taps per lane = ceil(row_len / 16)
 __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
                                                                int down, int T, long long j0, long long n_out, float *y,
                                                                int split)
@@ -344,7 +345,6 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
     const int part = static_cast<int>(wid - w * split);
     if (w >= up) return;
     const int row_len = 2 * T + 1;
-    const int ni = (row_len + 15) >> 4;
     const long long jj0 = (w - (j0 % up) + up) % up;  // first output of this row
     if (jj0 >= n_out) return;
     const long long g_total = (n_out - jj0 + up - 1) / up;
@@ -355,19 +355,34 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
     const long long q0 = c0 / up;  // the only 64-bit division: successive outputs of a row advance q by `down`
     const int p = static_cast<int>(c0 - q0 * up);
     const double *row = table + static_cast<long long>(p) * row_len;
-    double h[RS_MAX_NI];
+    // All loads below are unconditional (clamped index, masked afterwards): a branch around a load makes hipcc
+    // wait for every load separately, which is what made the first versions of this kernel latency-bound.
+    double h[NI];
 #pragma unroll
-    for (int i = 0; i < RS_MAX_NI; ++i) h[i] = (i < ni && sub + 16 * i < row_len) ? row[sub + 16 * i] : 0.0;
+    for (int i = 0; i < NI; ++i) h[i] = row[min(sub + 16 * i, row_len - 1)];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        if (sub + 16 * i >= row_len) h[i] = 0.0;
     for (long long g = g_lo + quarter; g < g_hi + quarter; g += 4) {  // all quarters iterate together
         const bool live = g < g_hi;
         const long long jj = jj0 + g * up;
         const long long q = q0 + g * down;
+        const long long top = q + T - sub;  // input index of this lane's first tap; tap i reads top - 16 i
         double acc = 0.0;
+        if (top - 16 * (NI - 1) >= 0 && top < n_in) {
+            // interior (almost always): one 64-bit base, immediate offsets, no clamps
+            const float *xp = x + top;
+            float xv[NI];
 #pragma unroll
-        for (int i = 0; i < RS_MAX_NI; ++i) {
-            if (i < ni) {
-                const long long nidx = q + T - (sub + 16 * i);
-                if (live && nidx >= 0 && nidx < n_in) acc = fma(h[i], static_cast<double>(x[nidx]), acc);
+            for (int i = 0; i < NI; ++i) xv[i] = xp[-16 * i];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc = fma(h[i], static_cast<double>(live ? xv[i] : 0.f), acc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const long long nidx = top - 16 * i;
+                const float v = x[min(max(nidx, 0LL), n_in - 1)];
+                acc = fma(h[i], static_cast<double>((live && nidx >= 0 && nidx < n_in) ? v : 0.f), acc);
             }
         }
 #pragma unroll
@@ -539,10 +554,17 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
     const int64_t g_total = (n_out + up - 1) / up;  // outputs per polyphase row
     const int split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(16, (g_total + 31) / 32)));
-    hipLaunchKernelGGL(k_resample, grid1d(static_cast<int64_t>(up) * split, RS_WAVES), dim3(RS_WAVES * kWave), 0,
-                       as_stream(stream), static_cast<const float *>(x_dev), (long long)n_in,
-                       static_cast<const double *>(table_dev), (int)up, (int)down, (int)T, (long long)j0, (long long)n_out,
-                       static_cast<float *>(y_dev), split);
+    const dim3 grid = grid1d(static_cast<int64_t>(up) * split, RS_WAVES), block(RS_WAVES * kWave);
+    const int ni = (2 * T + 1 + 15) / 16;
+#define IQA_RS_LAUNCH(NI)                                                                                          \
+    hipLaunchKernelGGL((k_resample<NI>), grid, block, 0, as_stream(stream), static_cast<const float *>(x_dev),     \
+                       (long long)n_in, static_cast<const double *>(table_dev), (int)up, (int)down, (int)T,        \
+                       (long long)j0, (long long)n_out, static_cast<float *>(y_dev), split)
+    if (ni <= 5) IQA_RS_LAUNCH(5);
+    else if (ni <= 6) IQA_RS_LAUNCH(6);
+    else if (ni <= 8) IQA_RS_LAUNCH(8);
+    else IQA_RS_LAUNCH(12);
+#undef IQA_RS_LAUNCH
     return check_launch("k_resample");
 }
 
