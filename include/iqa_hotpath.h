@@ -122,7 +122,12 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
  */
 typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
-    int32_t reserved;          /* diagnostics flags, 0 in production */
+    int32_t reserved;          /* data-path variant + diagnostics flags.  0 = per-lane row loads; 64 = block-wide
+                                * contiguous LDS-DMA ring (needs iqa_mfma_ring_bytes(D) > 0 and a single k-step
+                                * range; LDS = ring + 8*(outputs_per_block+160); it keeps 256*S1 + S2 in one int32, so the
+                                * fragments must come from a quantisation that bounds it: dsp_plan.plan_mfma(acc32=True));
+                                * 4 / 4|8 = per-wave staged
+                                * variants; bits 0,1,4,5 are timing diagnostics, never set in production */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
     void *debug_stamps;        /* NULL in production; diagnostics builds write per-wave cycle stamps here
@@ -135,6 +140,11 @@ typedef struct {
     void *partial_out_dev;       /* double2[n_out], written when finalize == 0 */
 } iqa_mfma_params;
 int64_t iqa_mfma_afrag_bytes(int32_t decimation);
+/* LDS bytes the ring variant (reserved = 64) spends on its data ring for this decimation; 0 = variant not
+ * applicable (it needs D % 4 == 0 and D <= 256).  Every tile of 32 data rows is fetched as 2048*ceil(2D/32)
+ * contiguous bytes, so the last output of a ring pass must satisfy
+ * (m_last - 1)*D + 512*ceil(2D/32) < consumed + n_frames. */
+int64_t iqa_mfma_ring_bytes(int32_t decimation);
 int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,
                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first, int64_t n_out,
                         void *z_out_dev, void *stream);

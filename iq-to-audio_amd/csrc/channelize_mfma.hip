@@ -30,77 +30,12 @@
 //
 // Lane maps of v_mfma_i32_32x32x32_i8 were verified on hardware with probe/mfma_i8_probe.hip:
 //   A[row=l&31][k=16(l>>5)+j], B[k=16(l>>5)+j][col=l&31], C: col=l&31, row=(r&3)+8(r>>2)+4(l>>5).
-#include "common.h"
+#include "mfma_common.h"
 
+#include <cmath>
 #include <type_traits>
 
 namespace iqa {
-
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef v4i_t v4i_a4 __attribute__((aligned(4)));
-typedef int v16i_t __attribute__((ext_vector_type(16)));
-
-constexpr int MF_WAVES = 8;  // one block per CU, two waves per SIMD, tap fragments shared by all eight
-constexpr int MF_THREADS = MF_WAVES * kWave;
-constexpr int MF_Q = 64;          // q slots per output component (needs ceil(L/D) <= 64)
-constexpr int MF_ROWTILES = 4;    // 2 components x 64 q = 128 rows
-constexpr int MF_KSTEP_BYTES = MF_ROWTILES * 2 * 1024;  // tap fragments per k step
-
-struct MfmaArgs {
-    const v4i_t *afrag;  // [ksteps][rowtile 4][piece 2][lane 64] 16-byte tap fragments
-    const int *raw;      // capture frames as dwords (lo half = I, hi half = Q)
-    float2 *out;         // out[i] = z[m_lo + i]
-    long long consumed, m_lo, n_out;
-    int D, ksteps, range, debug;
-    int k_first;      // first k step of this pass (K split over passes when the tap fragments exceed LDS)
-    int col_shift;    // 64 * q-group of this pass (filters with ceil(L/D) > 64 are split into q-groups)
-    int finalize;     // 1: add partial_in, rotate/scale and store z; 0: store the raw sums to partial_out
-    const double2 *partial_in;
-    double2 *partial_out;
-    unsigned long long *stamps;  // diagnostics only (debug bit 1): per-wave cycle anatomy
-    double unit, c_re, c_im;
-    int conj_sum, rotate;
-    unsigned long long rot_step, rot_base;
-    float sc_re, sc_im;
-};
-
-// emission shared by both kernels: output m0+i sits at position 64+i of the S1/S2 arrays
-template <int THREADS>
-__device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, int acc_len, int cnt, long long i0,
-                                          long long m0, int tid)
-{
-    for (int i = tid; i < cnt; i += THREADS) {
-        const int pos = MF_Q + i;
-        const double s1r = s_acc[pos], s1i = s_acc[acc_len + pos];
-        const double s2r = s_acc[2 * acc_len + pos], s2i = s_acc[3 * acc_len + pos];
-        double d_re = (s1r * 65536.0 + s2r * 256.0 + a.c_re) * a.unit;
-        double d_im = (s1i * 65536.0 + s2i * 256.0 + a.c_im) * a.unit;
-        if (a.partial_in != nullptr) {
-            const double2 pr = a.partial_in[i0 + i];
-            d_re += pr.x;
-            d_im += pr.y;
-        }
-        if (!a.finalize) {
-            a.partial_out[i0 + i] = make_double2(d_re, d_im);
-            continue;
-        }
-        float my_re = static_cast<float>(d_re);
-        float my_im = static_cast<float>(d_im);
-        if (a.conj_sum) my_im = -my_im;
-        float yr = my_re, yi = my_im;
-        if (a.rotate) {
-            const unsigned long long m = static_cast<unsigned long long>(m0 + i);
-            const unsigned long long ph = a.rot_base + m * a.rot_step;
-            const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
-            double s, c;
-            sincospi(2.0 * frac, &s, &c);
-            const float cf = static_cast<float>(c), sf = static_cast<float>(s);
-            yr = my_re * cf - my_im * sf;
-            yi = my_re * sf + my_im * cf;
-        }
-        a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
-    }
-}
 
 __global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs a)
 {
@@ -486,6 +421,13 @@ __global__ __launch_bounds__(WAVES *kWave, WAVES / 4) void k_channelize_mfma_s16
 
 using namespace iqa;
 
+extern "C" int64_t iqa_mfma_ring_bytes(int32_t decimation)
+{
+    // LDS bytes of the ring kernel's data ring for this decimation, or 0 when the ring kernel does not apply
+    if (decimation < 1 || !mfma_ring_supported(decimation)) return 0;
+    return static_cast<int64_t>(mfma_ring_lds_bytes((2 * decimation + 31) / 32));
+}
+
 extern "C" int64_t iqa_mfma_afrag_bytes(int32_t decimation)
 {
     // bytes of tap fragments for ALL k steps of one q-group (a pass may use a sub-range of k steps)
@@ -530,10 +472,22 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     if (f_min < 0 || f_max >= n_frames || f_max_full >= n_frames)
         return fail_inval("MFMA channelizer range reads outside the block (use iqa_channelize for the edges)");
     const int64_t acc_len = full_tiles * 32 + MF_Q + 4;
-    const bool staged = (q->reserved & 4) != 0;
+    const bool ring = (q->reserved & 64) != 0;  // block-wide contiguous LDS-DMA ring (channelize_ring.hip)
+    const bool staged = !ring && (q->reserved & 4) != 0;
     const bool waves12 = staged && (q->reserved & 8) != 0;  // 12-wave blocks (three waves per SIMD), ring of 3
     const size_t st_bytes = staged ? (waves12 ? 12 * 3 : 8 * 4) * static_cast<size_t>(ST_SLOT_BYTES) : 0;
-    const size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int) + st_bytes;
+    size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int) + st_bytes;
+    if (ring) {
+        if (!mfma_ring_supported(static_cast<int>(D)) || k_first != 0 || ksteps != ksteps_all)
+            return fail_inval("the ring kernel needs D % 4 == 0, D <= 256 and all k steps in one pass");
+        // a slot is filled in whole 1 KiB chunks: every tile reads 2048*ksteps bytes from its first frame
+        const int64_t slot_frames = 512LL * ksteps;
+        const int64_t t_last = m_first + (blocks - 1) * range - MF_Q - col_shift + (last_tiles - 1) * 32;
+        const int64_t t_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q - col_shift + (full_tiles - 1) * 32 : t_last;
+        if (t_last * D + 1 - consumed + slot_frames > n_frames || t_full * D + 1 - consumed + slot_frames > n_frames)
+            return fail_inval("ring kernel range reads outside the block (use iqa_channelize for the edges)");
+        lds = mfma_ring_lds_bytes(ksteps) + 2 * acc_len * sizeof(int);  // one int32 (256*S1 + S2) per output component
+    }
     if (lds > 160 * 1024) return fail_inval("tap fragments + accumulators exceed 160 KiB of LDS");
 
     MfmaArgs a;
@@ -562,6 +516,17 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     a.rot_base = p->rot_base;
     a.sc_re = p->out_scale_re;
     a.sc_im = p->out_scale_im;
+    {
+        // rotation between outputs 256 apart, for the ring kernel's recurrence: frac(256*rot_step / 2^64) turns
+        const unsigned long long st = p->rot_step * 256ULL;
+        const double turns = static_cast<double>(st >> 11) * (1.0 / 9007199254740992.0);
+        a.rotd_re = std::cos(2.0 * M_PI * turns);
+        a.rotd_im = std::sin(2.0 * M_PI * turns);
+    }
+    if (ring) {
+        mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream));
+        return check_launch("k_channelize_mfma_s16_ring");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16),

@@ -1,0 +1,259 @@
+// channelize_ring.hip -- int8-MFMA channelizer with a block-wide contiguous LDS-DMA ring (gfx950).
+//
+// Same mathematics, tap fragments, accumulators and emission as channelize_mfma.hip (reference
+// processing.py:268-279, 289-297, 325-346, 354-360); what changes is how the capture reaches the matrix
+// cores.  The kernels of channelize_mfma.hip let every lane (or every group of four lanes) fetch its own
+// row, so one wave-instruction touches 16-64 different 416-byte rows: measured, that address pattern alone
+// caps the data path at ~3.8 TB/s.  Here the block streams the capture exactly as it lies in memory:
+//
+//   * the data columns a block needs are ONE contiguous run of the capture; it is cut into tiles of 32 rows
+//     (32*D frames) and copied into LDS slots by global_load_lds_dwordx4 in chunks of 1 KiB per
+//     wave-instruction (64 lanes x 16 consecutive bytes): 8-9 cache lines per instruction instead of 64;
+//   * 8 waves, two per SIMD.  Wave (rt, cp): rt = one of the four tap-row tiles (32 of the 128 rows),
+//     cp = column-tile parity.  A round = two column tiles (cp 0/1); the four waves of a parity read the
+//     same slot (ds_read_b128 at row stride 4*D) and each multiplies it with ITS 32 tap rows, whose
+//     fragments (8*KS registers) stay in registers for the whole block -- no tap traffic through LDS;
+//   * ring of R rounds: the DMAs of round r+R-1 are issued during round r, one per k step, by two waves
+//     of each parity (one issuing wave per SIMD), behind a counted s_waitcnt vmcnt; one s_barrier per
+//     round publishes the landed slots and frees the oldest.
+//
+// A slot is 2048*KS bytes >= 31 rows + one K-padded row (KS = ceil(2D/32) k steps), so an issuing wave
+// issues exactly KS DMAs per round.  Needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
+#include "mfma_common.h"
+
+#include <cmath>
+#include <type_traits>
+
+namespace iqa {
+
+typedef __attribute__((address_space(3))) void ring_lds_t;
+
+constexpr int RG_WAVES = 8;
+constexpr int RG_THREADS = RG_WAVES * kWave;
+constexpr int RG_MAX_KS = 16;
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void *)p));
+}
+
+__host__ __device__ constexpr int ring_rounds(int ks) { return ks <= 8 ? 3 : 2; }
+
+struct RingCtx {
+    char *smem;
+    int *s_acc;
+    const char *stream0;  // this lane's source byte of chunk (rt & 1) of tile 0
+    long long tile_bytes;
+    int tiles, rounds, acc_len, lane_off, rt, cp, col, h;
+};
+
+// The main loop of one wave.  ISSUER: this wave feeds the ring (chunks 2i + (rt & 1) of its parity's slot).
+// DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
+template <int KS, int DBG, bool ISSUER>
+__device__ __forceinline__ void ring_main(const RingCtx &c, const v4i_t (&fq)[KS][2])
+{
+    constexpr int R = ring_rounds(KS);
+    constexpr int SLOT = 2048 * KS;
+    constexpr bool STREAM = ISSUER && !(DBG & 16);
+    const int rt = c.rt, cp = c.cp;
+    auto issue = [&](int tile, int slot, int i) {
+        const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes + i * 2048;
+        char *dst = c.smem + (slot * 2 + cp) * SLOT + (rt & 1) * 1024 + i * 2048;
+        __builtin_amdgcn_global_load_lds(src, (ring_lds_t *)dst, 16, 0, 0);
+    };
+    if (STREAM) {
+#pragma unroll
+        for (int rr = 0; rr < R - 1; ++rr)
+#pragma unroll
+            for (int i = 0; i < KS; ++i) issue(2 * rr + cp, rr, i);
+    }
+    const v16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int slot = 0;
+    for (int r = 0; r < c.rounds; ++r) {
+        // an issuing wave's DMAs of round r have landed once only those of the younger rounds are outstanding
+        const int younger = min(R - 2, c.rounds - 1 - r);
+        if (!STREAM) {
+            asm volatile("s_barrier" ::: "memory");
+        } else if (R >= 4 && younger == 2) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * KS) : "memory");
+        } else if (R >= 3 && younger == 1) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const bool pf = STREAM && (r + R - 1 < c.rounds);
+        const int pf_tile = 2 * (r + R - 1) + cp;
+        const int pf_slot = (slot == 0) ? R - 1 : slot - 1;  // the slot round r-1 has just left
+        const int t = 2 * r + cp;
+        if (t < c.tiles) {
+            const char *la = c.smem + (slot * 2 + cp) * SLOT + c.lane_off;
+            // PF is a compile-time copy of `pf`: the k loop stays one basic block.  An LDS-DMA is a store to LDS as
+            // far as the compiler knows, so it never moves a ds_read above an earlier issue(): the data fragments
+            // are read PD k steps ahead by hand, and a scheduling barrier per k step keeps them there.
+            auto tile_body = [&](auto pf_c) {
+                constexpr bool PF = decltype(pf_c)::value;
+                constexpr int PD = KS < 2 ? KS : 2;
+                v4i_t dd[KS][2];
+#pragma unroll
+                for (int ks = 0; ks < PD; ++ks) {
+                    dd[ks][0] = *reinterpret_cast<const v4i_t *>(la + 64 * ks);
+                    dd[ks][1] = *reinterpret_cast<const v4i_t *>(la + 64 * ks + 16);
+                }
+                v16i_t acc1, acc2;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
+                    v4i_t hi, lo;
+                    hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
+                    hi.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x07050301);
+                    hi.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x07050301);
+                    hi.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x07050301);
+                    lo.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200) ^ 0x80808080;
+                    lo.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x06040200) ^ 0x80808080;
+                    lo.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200) ^ 0x80808080;
+                    lo.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x06040200) ^ 0x80808080;
+                    if (ks + PD < KS) {
+                        dd[ks + PD][0] = *reinterpret_cast<const v4i_t *>(la + 64 * (ks + PD));
+                        dd[ks + PD][1] = *reinterpret_cast<const v4i_t *>(la + 64 * (ks + PD) + 16);
+                    }
+                    if (PF) issue(pf_tile, pf_slot, ks);
+                    if (DBG & 32) {
+                        asm volatile("" ::"v"(hi), "v"(lo));
+                    } else {
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], hi, ks ? acc1 : zero16, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], lo, ks ? acc2 : zero16, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (DBG & 32) acc1 = acc2 = zero16;
+                if (DBG & 1) {
+                    asm volatile("" ::"v"(acc1), "v"(acc2));
+                } else {
+                    // diagonal scatter into the block's sums (row = q, column = data row: output = row + column).
+                    // Written as inline asm on purpose: the compiler drains vmcnt to 0 before any LDS store it can see
+                    // while LDS-DMAs are in flight (it cannot tell the ring from the accumulators), which would serialise
+                    // the whole prefetch pipeline once per round.  These adds touch s_acc only, never the ring.
+                    const unsigned p =
+                        lds_addr(c.s_acc + (t * 32 + c.col + 4 * c.h + 1) + (rt >> 1) * c.acc_len + (rt & 1) * 32);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        // 256*S1 + S2 in ONE int32 (the host bounds the tap magnitudes so that this cannot overflow for
+                        // any input, dsp_plan.plan_mfma(acc32=True)); the shift-add is a VALU op the compiler can see, so
+                        // the MFMA -> VALU hazard distance is its business and the asm reads a VALU result
+                        const int comb = (acc1[q] << 8) + acc2[q];
+                        const int off = 4 * ((q & 3) + 8 * (q >> 2));
+                        asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(p), "v"(comb), "n"(off));
+                    }
+                }
+            };
+            if (pf) tile_body(std::true_type{});
+            else tile_body(std::false_type{});
+        } else if (pf) {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) issue(pf_tile, pf_slot, i);
+        }
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+}
+
+template <int KS, int DBG>
+__global__ __launch_bounds__(RG_THREADS, 2) void k_channelize_mfma_s16_ring(MfmaArgs a)
+{
+    constexpr int R = ring_rounds(KS);
+    constexpr int SLOT = 2048 * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RingCtx c;
+    c.rt = wave & 3;
+    c.cp = wave >> 2;
+    c.col = lane & 31;
+    c.h = lane >> 5;
+
+    const long long i0 = static_cast<long long>(blockIdx.x) * a.range;
+    const int cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - i0));
+    const long long m0 = a.m_lo + i0;
+    c.tiles = (cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
+    c.acc_len = c.tiles * 32 + MF_Q + 4;
+    c.rounds = (c.tiles + 1) >> 1;
+    c.smem = smem;
+    c.s_acc = reinterpret_cast<int *>(smem + R * 2 * SLOT);  // [Sre | Sim], acc_len ints each, S = 256*S1 + S2
+
+    // tap fragments of this wave's row tile: registers for the whole block
+    v4i_t fq[KS][2];
+    {
+        const v4i_t *fa = a.afrag + c.rt * 128 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) fq[ks][pc] = fa[(ks * 8 + pc) * 64];
+        // have them arrive here, before the first DMA: a later wait for them would drain the DMA queue with them
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(fq[ks][0]), "v"(fq[ks][1]));
+    }
+    {
+        v4i_t *z = reinterpret_cast<v4i_t *>(c.s_acc);
+        for (int i = tid; i < c.acc_len / 2; i += RG_THREADS) z[i] = v4i_t{0, 0, 0, 0};  // 2*acc_len ints, acc_len % 4 == 0
+    }
+    __syncthreads();
+
+    // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
+    const long long row_bytes = 4LL * a.D;
+    c.tile_bytes = 32 * row_bytes;
+    c.stream0 = reinterpret_cast<const char *>(a.raw) + 4 * ((m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
+                lane * 16 + (c.rt & 1) * 1024;
+    c.lane_off = c.col * static_cast<int>(row_bytes) + 32 * c.h;
+
+    // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
+    if ((c.rt >> 1) == c.cp) ring_main<KS, DBG, true>(c, fq);
+    else ring_main<KS, DBG, false>(c, fq);
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the asm ds_add are invisible to the compiler's counters
+    __syncthreads();
+    mfma_emit_rec<RG_THREADS>(a, c.s_acc, c.acc_len, cnt, i0, m0, tid);
+}
+
+bool mfma_ring_supported(int decimation)
+{
+    const int ks = (2 * decimation + 31) / 32;
+    return decimation >= 4 && (decimation & 3) == 0 && ks <= RG_MAX_KS;
+}
+
+size_t mfma_ring_lds_bytes(int ksteps) { return static_cast<size_t>(ring_rounds(ksteps)) * 2 * 2048 * ksteps; }
+
+template <int KS, int DBG>
+static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_ring<KS, DBG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_channelize_mfma_s16_ring<KS, DBG>), dim3(blocks), dim3(RG_THREADS), lds, stream, a);
+}
+
+void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    const int dbg = a.debug & (1 | 16 | 32);
+    if (dbg && a.ksteps == 7) {  // diagnostic instantiations exist for the benchmark shape only
+        switch (dbg) {
+            case 1: return ring_launch_one<7, 1>(a, blocks, lds, stream);
+            case 16: return ring_launch_one<7, 16>(a, blocks, lds, stream);
+            case 17: return ring_launch_one<7, 17>(a, blocks, lds, stream);
+            case 32: return ring_launch_one<7, 32>(a, blocks, lds, stream);
+            case 33: return ring_launch_one<7, 33>(a, blocks, lds, stream);
+            default: break;
+        }
+    }
+    switch (a.ksteps) {
+#define RG_CASE(K) case K: return ring_launch_one<K, 0>(a, blocks, lds, stream)
+        RG_CASE(1); RG_CASE(2); RG_CASE(3); RG_CASE(4); RG_CASE(5); RG_CASE(6); RG_CASE(7); RG_CASE(8);
+        RG_CASE(9); RG_CASE(10); RG_CASE(11); RG_CASE(12); RG_CASE(13); RG_CASE(14); RG_CASE(15); RG_CASE(16);
+#undef RG_CASE
+        default: break;
+    }
+}
+
+}  // namespace iqa

@@ -1,0 +1,131 @@
+// mfma_common.h -- types, argument block and the output emission shared by the int8-MFMA channelizer
+// kernels (channelize_mfma.hip: per-lane and per-wave-staged data paths; channelize_ring.hip: block-wide
+// contiguous LDS-DMA ring).  See channelize_mfma.hip for the mathematics.
+#pragma once
+
+#include "common.h"
+
+namespace iqa {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef v4i_t v4i_a4 __attribute__((aligned(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+constexpr int MF_WAVES = 8;  // one block per CU, two waves per SIMD, tap fragments shared by all eight
+constexpr int MF_THREADS = MF_WAVES * kWave;
+constexpr int MF_Q = 64;          // q slots per output component (needs ceil(L/D) <= 64)
+constexpr int MF_ROWTILES = 4;    // 2 components x 64 q = 128 rows
+constexpr int MF_KSTEP_BYTES = MF_ROWTILES * 2 * 1024;  // tap fragments per k step
+
+struct MfmaArgs {
+    const v4i_t *afrag;  // [ksteps][rowtile 4][piece 2][lane 64] 16-byte tap fragments
+    const int *raw;      // capture frames as dwords (lo half = I, hi half = Q)
+    float2 *out;         // out[i] = z[m_lo + i]
+    long long consumed, m_lo, n_out;
+    int D, ksteps, range, debug;
+    int k_first;      // first k step of this pass (K split over passes when the tap fragments exceed LDS)
+    int col_shift;    // 64 * q-group of this pass (filters with ceil(L/D) > 64 are split into q-groups)
+    int finalize;     // 1: add partial_in, rotate/scale and store z; 0: store the raw sums to partial_out
+    const double2 *partial_in;
+    double2 *partial_out;
+    unsigned long long *stamps;  // diagnostics only (debug bit 1): per-wave cycle anatomy
+    double unit, c_re, c_im;
+    int conj_sum, rotate;
+    unsigned long long rot_step, rot_base;
+    float sc_re, sc_im;
+    double rotd_re, rotd_im;  // exp(j*2*pi*256*rot_step): rotation between outputs 256 apart (ring kernel emission)
+};
+
+// emission shared by both kernels: output m0+i sits at position 64+i of the S1/S2 arrays
+template <int THREADS>
+__device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, int acc_len, int cnt, long long i0,
+                                          long long m0, int tid)
+{
+    for (int i = tid; i < cnt; i += THREADS) {
+        const int pos = MF_Q + i;
+        const double s1r = s_acc[pos], s1i = s_acc[acc_len + pos];
+        const double s2r = s_acc[2 * acc_len + pos], s2i = s_acc[3 * acc_len + pos];
+        double d_re = (s1r * 65536.0 + s2r * 256.0 + a.c_re) * a.unit;
+        double d_im = (s1i * 65536.0 + s2i * 256.0 + a.c_im) * a.unit;
+        if (a.partial_in != nullptr) {
+            const double2 pr = a.partial_in[i0 + i];
+            d_re += pr.x;
+            d_im += pr.y;
+        }
+        if (!a.finalize) {
+            a.partial_out[i0 + i] = make_double2(d_re, d_im);
+            continue;
+        }
+        float my_re = static_cast<float>(d_re);
+        float my_im = static_cast<float>(d_im);
+        if (a.conj_sum) my_im = -my_im;
+        float yr = my_re, yi = my_im;
+        if (a.rotate) {
+            const unsigned long long m = static_cast<unsigned long long>(m0 + i);
+            const unsigned long long ph = a.rot_base + m * a.rot_step;
+            const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
+            double s, c;
+            sincospi(2.0 * frac, &s, &c);
+            const float cf = static_cast<float>(c), sf = static_cast<float>(s);
+            yr = my_re * cf - my_im * sf;
+            yi = my_re * sf + my_im * cf;
+        }
+        a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+    }
+}
+
+// Emission of the ring kernel: the same arithmetic as mfma_emit, but the float64 sincospi is evaluated once
+// per thread; the outputs a thread owns are THREADS (256 or 512) apart, so their rotations follow from a
+// float64 complex recurrence with the host-computed step (error ~1e-16 per step, far below the float32
+// rounding the rotation is applied in).
+template <int THREADS>
+__device__ __forceinline__ void mfma_emit_rec(const MfmaArgs &a, const int *s_acc, int acc_len, int cnt, long long i0,
+                                              long long m0, int tid)
+{
+    static_assert(THREADS == 256 || THREADS == 512, "rotd is the step for 256 outputs");
+    const double st_re = THREADS == 256 ? a.rotd_re : a.rotd_re * a.rotd_re - a.rotd_im * a.rotd_im;
+    const double st_im = THREADS == 256 ? a.rotd_im : 2.0 * a.rotd_re * a.rotd_im;
+    double wc = 1.0, ws = 0.0;
+    if (a.finalize && a.rotate && tid < cnt) {
+        const unsigned long long m = static_cast<unsigned long long>(m0 + tid);
+        const unsigned long long ph = a.rot_base + m * a.rot_step;
+        const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
+        sincospi(2.0 * frac, &ws, &wc);
+    }
+    for (int i = tid; i < cnt; i += THREADS) {
+        const int pos = MF_Q + i;
+        // the ring kernel keeps S = 256*S1 + S2 per component in one int32
+        const double sr = s_acc[pos], si = s_acc[acc_len + pos];
+        double d_re = (sr * 256.0 + a.c_re) * a.unit;
+        double d_im = (si * 256.0 + a.c_im) * a.unit;
+        if (a.partial_in != nullptr) {
+            const double2 pr = a.partial_in[i0 + i];
+            d_re += pr.x;
+            d_im += pr.y;
+        }
+        if (!a.finalize) {
+            a.partial_out[i0 + i] = make_double2(d_re, d_im);
+            continue;
+        }
+        float my_re = static_cast<float>(d_re);
+        float my_im = static_cast<float>(d_im);
+        if (a.conj_sum) my_im = -my_im;
+        float yr = my_re, yi = my_im;
+        if (a.rotate) {
+            const float cf = static_cast<float>(wc), sf = static_cast<float>(ws);
+            yr = my_re * cf - my_im * sf;
+            yi = my_re * sf + my_im * cf;
+            const double nc = wc * st_re - ws * st_im;
+            ws = fma(wc, st_im, ws * st_re);
+            wc = nc;
+        }
+        a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+    }
+}
+
+// launcher of the ring kernels (channelize_ring.hip); returns false when no instantiation covers `ksteps`
+bool mfma_ring_supported(int decimation);
+size_t mfma_ring_lds_bytes(int ksteps);  // LDS taken by the data ring (the S1/S2 accumulators follow it)
+void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds_bytes, hipStream_t stream);
+
+}  // namespace iqa

@@ -235,9 +235,14 @@ def _mfma_layout(ntaps: int, decimation: int, group: int):
     return ksteps, kc, ok, flat
 
 
-def plan_mfma(plan: ChannelPlan) -> MfmaPlan:
+def plan_mfma(plan: ChannelPlan, acc32: bool = False) -> MfmaPlan:
     """Quantise the (already NCO-rotated, scaled) taps to 16-bit fixed point and lay them out as
     the A operand of v_mfma_i32_32x32x32_i8.
+
+    ``acc32``: the ring kernel keeps 256*S1 + S2 of an output component in ONE int32.  The tap unit is then
+    enlarged (taps of ~14 bits for the standard 12.5 kHz filters) until
+    sum_k 128*(257|q1_k| + |q2_k|) < 2^31 over the rows of a component, so that the sum cannot overflow for
+    ANY int16 input; everything stays exact integer arithmetic.
 
     Rows: row = comp*64 + (q-1) within a q-group of 64 tap rows; columns kap = 2*rho + c over one
     data row of D frames:
@@ -270,9 +275,18 @@ def plan_mfma(plan: ChannelPlan) -> MfmaPlan:
         a[MFMA_Q:, 1 : 2 * D : 2] = gre
         amax = float(np.abs(a).max())
         unit = amax / 32639.0 if amax > 0 else 1.0
-        t = np.rint(a * (1.0 / unit)).astype(np.int32)
-        q2 = ((t + 128) & 255) - 128
-        q1 = (t - q2) >> 8
+        while True:
+            t = np.rint(a * (1.0 / unit)).astype(np.int32)
+            q2 = ((t + 128) & 255) - 128
+            q1 = (t - q2) >> 8
+            if not acc32:
+                break
+            # |256*S1 + S2| <= sum 128*(257|q1| + |q2|) over one component's rows (|hi|, |lo'| <= 128)
+            bound = max(int((128 * (257 * np.abs(q1[r]).astype(np.int64) + np.abs(q2[r]))).sum())
+                        for r in (slice(0, MFMA_Q), slice(MFMA_Q, 2 * MFMA_Q)))
+            if bound < 2**31 - 1:
+                break
+            unit *= max(1.02, bound / (2**31 - 1) * 1.001)
         frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
         frag[:, :, 0] = q1.reshape(-1)[flat]
         frag[:, :, 1] = q2.reshape(-1)[flat]

@@ -149,9 +149,11 @@ class _ChannelKernel:
     #: set to False to force the float32 VALU kernel everywhere (tests compare the two)
     use_mfma = True
     #: data path of the MFMA kernel: "plain" (per-lane row loads into VGPRs), "staged8" (8 waves, LDS-DMA ring of 4),
-    #: "staged12" (12 waves = three per SIMD, ring of 3, tap fragments read just in time)
-    mfma_variant = "plain"
-    _VARIANT = {"plain": (0, 0), "staged8": (4, 8 * 4 * 2048), "staged12": (4 | 8, 12 * 3 * 2048)}  # flags, LDS ring bytes
+    #: "staged12" (12 waves = three per SIMD, ring of 3, tap fragments read just in time), "ring" (4 waves, the
+    #: block streams its contiguous run of the capture through an LDS-DMA ring, tap fragments in registers;
+    #: falls back to "plain" where it does not apply: D % 4 != 0, D > 256, multi-range passes)
+    mfma_variant = "ring"
+    _VARIANT = {"plain": (0, 0), "staged8": (4, 8 * 4 * 2048), "staged12": (4 | 8, 12 * 3 * 2048), "ring": (64, 0)}  # flags, LDS ring bytes
     mfma_min_outputs = 32768
 
     def __init__(self, plan: P.ChannelPlan):
@@ -166,17 +168,21 @@ class _ChannelKernel:
             out_scale_re=float(np.real(plan.out_scale)), out_scale_im=float(np.imag(plan.out_scale)),
         )
         self.mfma = None  # planned lazily, the first time a block is long enough to use it
+        self._ring_bytes = int(N.lib().iqa_mfma_ring_bytes(plan.decimation)) if plan.fmt == "s16" else 0
         self._mfma_ok = bool(self.use_mfma and P.mfma_supported(plan))
 
     def _ensure_mfma(self):
         if self.mfma is None:
-            mp = P.plan_mfma(self.plan)
+            ring = self.mfma_variant == "ring" and bool(self._ring_bytes) and -(-2 * self.plan.decimation // 32) <= P.MFMA_MAX_KSTEPS_PER_PASS
+            mp = P.plan_mfma(self.plan, acc32=ring)
             self.mfma = mp
             self.afrag_dev = [D.from_numpy(g.afrag.reshape(-1).view(np.uint8)) for g in mp.groups]
             self.mfma_params = []
             for ps in mp.passes:
                 # one 8-wave block per CU owns all 160 KiB of LDS: this pass's tap fragments + 16 B per output
                 variant = self.mfma_variant
+                if variant == "ring" and not ring:
+                    variant = "plain"
                 if self._range_max(ps.k_count, variant) < 512:  # the staging ring does not fit LDS next to the taps
                     variant = "plain"
                 rng = self._range_max(ps.k_count, variant)
@@ -188,6 +194,9 @@ class _ChannelKernel:
         return self.mfma
 
     def _range_max(self, k_count: int, variant: str) -> int:
+        if variant == "ring":  # tap fragments live in registers: LDS = data ring + accumulators
+            lds = 160 * 1024 - self._ring_bytes
+            return int(min(8192, (lds // 8 - 160) // 32 * 32))
         lds = 160 * 1024 - k_count * P.MFMA_KSTEP_BYTES - self._VARIANT[variant][1]
         return int(min(6144, (lds // 16 - 160) // 32 * 32))
 
@@ -215,11 +224,14 @@ class _ChannelKernel:
             ksteps = -(-2 * d // 32)
             n_groups = max(1, -(-(-(-self.plan.ntaps // d)) // P.MFMA_Q))
             m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, d, ksteps, n_groups)
+            if self.mfma_variant == "ring" and self._ring_bytes:
+                # a ring tile is fetched as 2048*ksteps contiguous bytes from its first frame
+                m_b = min(m_b, (n_frames + consumed - 512 * ksteps - 1) // d + 2)
             if m_b - m_a >= self.mfma_min_outputs:
                 mp = self._ensure_mfma()
                 n_int = m_b - m_a
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
-                self.last_kernel = "k_channelize_mfma_s16"
+                self.last_kernel = "k_channelize_mfma_s16" + ("_ring" if self._pass_variant[-1] == "ring" else "")
                 partial = D.empty(2 * n_int, "float64") if len(mp.passes) > 1 else None
                 if events:
                     events[0].record()
