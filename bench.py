@@ -9,6 +9,10 @@ effective 4 194 304, D = 104, 6401 taps).
 One *step* = one pass of the whole hot path over the capture:
   mixer-sign probe -> fused ingest+mix+FIR+decimate -> discriminator -> de-emphasis scan ->
   peak/clip -> 48 kHz polyphase resample -> PCM16 -> D2H of the audio [-> RCCL gather at N>1].
+Steps are queued through processing.ResidentCaptureRunner (a batch of captures with one set of settings):
+no host<->device synchronisation inside a step, the channelizer runs speculatively for mixer sign +1
+behind the probes (checked when the capture is collected), and the D2H of one capture overlaps the
+kernels of the next.
 The capture is resident in HBM before the timed region (the first 5 s are the reference's
 seed-42 generator, tiled to 60 s in HBM -- SURVEY.md section 8(d)).
 
@@ -44,7 +48,7 @@ def parse_args():
     ap.add_argument("--sample-rate", type=float, default=10e6)
     ap.add_argument("--unique-seconds", type=float, default=5.0, help="seed-42 prefix generated on the host, then tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunks", type=int, default=5, help="reference chunks timed for the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
 
@@ -57,7 +61,7 @@ def main() -> None:
     from iq_to_audio_amd import _dev as D
     from iq_to_audio_amd import dsp_plan as P
     from iq_to_audio_amd.benchmark import synthetic_iq_s16
-    from iq_to_audio_amd.processing import ChannelDemod, MixSignProbe, Resampler48k
+    from iq_to_audio_amd.processing import ResidentCaptureRunner
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,52 +91,32 @@ def main() -> None:
     del tile
     torch.cuda.synchronize()
 
-    n_dec = -(-n_total // d)
-    starts = P.chunk_output_starts(chunk, d, 0, n_total)
-    rs = Resampler48k(fs_ch)
-    n48 = rs.plan.n_out(n_dec)
-    pcm_host = torch.empty(n48, dtype=torch.int16).pin_memory()
+    # one runner per configuration: plans are made once, every step queues probes + channelizer + demod/resample/PCM16
+    # (compute stream) and the D2H (egress stream) without a host<->device synchronisation
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
+                                   n_frames=n_total, demod_mode="nfm", deemph_us=300.0, agc_enabled=True, fmt="s16")
+    n48 = runner.n48
     # finished 48 kHz PCM16 audio of every capture is gathered on rank 0 (as bytes: RCCL has no int16 type)
     gathered = [torch.empty(2 * n48, dtype=torch.uint8, device=D.device()) for _ in range(world)] if (world > 1 and rank == 0) else None
-    io_stream = torch.cuda.Stream()  # audio egress (D2H, RCCL gather) overlaps the next step's kernels
     pending = []
     ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
-    z = D.empty(n_dec, "complex64")
-    audio = D.empty(n_dec, "float32")
-
-    kernel_name = ["?"]
+    tickets = []
 
     def step(i: int):
-        # the two mixer-sign probes run on the GPU while the host plans the channelizer for the likely
-        # sign (+1) and stages the demodulator's small buffers; the read-back of the probe is the only
-        # host<->device synchronisation of a step
-        probe = MixSignProbe(raw[: 2 * min(chunk, n_total)], fs, f_off, taps, d, fmt="s16")
-        chan = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt="s16")
-        chan.plan_ahead()
-        dem = ChannelDemod("nfm", fs_ch, deemph_us=300.0, agc_enabled=True)
-        dem.prepare(n_dec, starts)
-        sign = probe.result()
-        if sign != 1:
-            chan = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=sign, decimation=d, fmt="s16")
-        chan.process(raw, out_dev=z, events=(ev_k0[i], ev_k1[i]))
-        kernel_name[0] = chan._kernel.last_kernel
-        dem.process(z, starts, audio)
-        y48 = rs.process(audio)
-        pcm = rs.to_pcm16(y48)
-        done = torch.cuda.Event()
-        done.record()
-        io_stream.wait_event(done)
-        with torch.cuda.stream(io_stream):
-            pcm.record_stream(io_stream)
-            pcm_host.copy_(pcm, non_blocking=True)
-            if world > 1:
+        t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]))
+        tickets.append(t)
+        if world > 1:
+            with torch.cuda.stream(runner.egress):  # behind this capture's D2H, overlapping the next capture's kernels
                 while pending:
                     pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
-                pending.append(dist.gather(pcm.view(torch.uint8), gathered, dst=0, async_op=True))
-        return sign, dem, y48
+                pending.append(dist.gather(t["pcm"].view(torch.uint8), gathered, dst=0, async_op=True))
+        return t
 
     def fence():
+        for t in tickets:
+            runner.collect(t)
+        del tickets[:]
         while pending:
             pending.pop().wait()
         if world > 1:
@@ -151,10 +135,13 @@ def main() -> None:
     gc.disable()  # a generation-2 collection in the middle of a 1.3 ms step shows up as a 10-50 ms stall
     t0 = time.perf_counter()
     marks = []
+    last = None
     for i in range(args.steps):
-        sign, dem, y48 = step(args.warmup + i)
+        last = step(args.warmup + i)
         marks.append(time.perf_counter() - t0)
+    res = runner.collect(last)
     fence()
+    sign, audio, kernel_name = res["sign"], res["audio"], [res["kernel"]]
     if os.environ.get("IQA_BENCH_DEBUG"):
         stats1 = torch.cuda.memory_stats()
         keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")
@@ -222,11 +209,14 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_ref as O
 
-        n_cpu = min(n_unique, args.cpu_chunks * chunk)
+        # bounded sample: ~cpu_seconds of CPU work at the ~19 MS/s this port runs at, in whole reference chunks,
+        # of the SAME tiled capture the GPU processed (so the parity check below covers the whole sample)
+        n_cpu = min(n_total, max(1, int(round(args.cpu_seconds * 19.0e6 / chunk))) * chunk)
+        host_cpu = np.tile(host, -(-2 * n_cpu // host.size))[: 2 * n_cpu]
         t1 = time.perf_counter()
-        ref = O.run_chain(host[: 2 * n_cpu], sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+        ref = O.run_chain(host_cpu, sample_rate=fs, freq_offset=f_off, keep_decimated=False)
         cpu_s = time.perf_counter() - t1
-        # parity of the benchmarked GPU output against the oracle on the same prefix
+        # parity of the benchmarked GPU output against the oracle on the same sample
         got = audio[: ref.audio.size].cpu().numpy()
         err = float(np.sqrt(np.mean((got.astype(np.float64) - ref.audio) ** 2)))
         out["cpu_baseline"] = {
@@ -236,7 +226,7 @@ def main() -> None:
             "kind": "port",
             "sample": f"first {n_cpu} frames ({n_cpu / fs:.2f} s of signal) of the same capture, oracle/cpu_ref.run_chain "
                       f"(fp64 NCO + complex128 131072-pt scipy.fft overlap-save + slice decimate + NFM), "
-                      f"{cpu_s:.1f} s on {os.cpu_count()} host cpus (1-D FFTs are single-threaded)",
+                      f"{cpu_s:.1f} s on 1 of {os.cpu_count()} host cpus (1-D FFTs are single-threaded)",
         }
         out["parity"] = {"rms_err_vs_oracle_fs_channel": err, "samples_compared": int(ref.audio.size), "bar": 1e-4}
 

@@ -1,13 +1,15 @@
-"""Scratch: cProfile of bench.py's host side (where does a step spend host time?)."""
+"""Scratch: cProfile of bench.py's host side (where does a step spend host time?).  A short capture makes the
+GPU work negligible, so ms_per_step ~ host time per step."""
 import cProfile, pstats, sys, io
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.argv = ["bench.py", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--seconds", "60"]
+sys.argv = ["bench.py", "--steps", "200", "--warmup", "5", "--no-cpu-baseline", "--seconds", "2", "--unique-seconds", "1"]
 import bench
 pr = cProfile.Profile()
 pr.enable()
 bench.main()
 pr.disable()
-s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18)
-print(s.getvalue()[:4000], file=sys.stderr)
+for key in ("tottime", "cumulative"):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+    print(s.getvalue()[:9000], file=sys.stderr)

@@ -17,6 +17,7 @@ import os
 outs = {}
 for dbg in [int(x) for x in os.environ.get('DBG', '0,4,12').split(',')]:
     PR._ChannelKernel.mfma_variant = {0: "plain", 4: "staged8", 12: "staged12", 64: "ring"}[dbg & 76]
+    PR._KERNEL_CACHE.clear()
     ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
     ch.plan_ahead(); ch._kernel.mfma_params[0].reserved |= (dbg & ~76)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +30,7 @@ for dbg in [int(x) for x in os.environ.get('DBG', '0,4,12').split(',')]:
 print('variants bitwise equal:', {k: bool(torch.equal(outs[k], list(outs.values())[0])) for k in outs}, 'max abs diff vs first:', {k: float((outs[k] - list(outs.values())[0]).abs().max()) for k in outs})
 if os.environ.get('NOSTAMPS'): sys.exit(0)
 PR._ChannelKernel.mfma_variant = 'plain'
+PR._KERNEL_CACHE.clear()
 # cycle anatomy from in-kernel stamps (diagnostic build path, debug bit 1)
 ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
 ch.plan_ahead()
@@ -44,6 +46,7 @@ print("per tile: loop %.0f cycles, of which scatter %.0f; ideal MFMA per tile %d
 
 # staged kernel: where does a k step go?  (sums over all k steps of a wave; shares, not absolute time)
 PR._ChannelKernel.mfma_variant = os.environ.get('STAMPV', 'staged12')
+PR._KERNEL_CACHE.clear()
 ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
 ch.plan_ahead()
 st.zero_()

@@ -451,6 +451,56 @@ def test_pipeline_end_to_end_wav(A, tmp_path):
         A.ProcessingPipeline(A.ProcessingConfig(in_path=wav, target_freq=4e8, center_freq=4e8, iq_order="xx")).run()
 
 
+def test_resident_capture_runner_batch_and_sign_speculation(A):
+    """processing.ResidentCaptureRunner: a batch of device-resident captures with one set of settings, every
+    capture queued without a host sync (speculative mixer sign +1, tail on a second stream).  Each capture's
+    48 kHz PCM16 must equal the oracle's (<= 1 LSB), captures must not bleed into each other through the two
+    buffer slots, and a capture whose probe picks sign -1 must come out as if the sign had been known."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.processing import ResidentCaptureRunner
+
+    fs, f_off, secs = 10e6, 25e3, 0.9
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    chunk = P.tune_chunk_size(fs, 1_048_576)
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    n = int(round(fs * secs))
+    caps = [O.synth_capture_s16(fs, secs, f_off, seed=42),      # sign +1
+            O.synth_capture_s16(fs, secs, -f_off, seed=43),     # carrier on the other side: the probe picks -1
+            O.synth_capture_s16(fs, secs, f_off, seed=44),
+            O.synth_capture_s16(fs, secs, f_off, seed=45)]
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
+                                   n_frames=n, demod_mode="nfm")
+    devs = [D.to_device(c.reshape(-1), "int16") for c in caps]
+    tickets = [runner.submit(x) for x in devs]   # submit 3 and 4 collect 1 and 2 to free their slots
+    got = []
+    for t in tickets:
+        r = runner.collect(t)
+        got.append((r["sign"], None if t is not tickets[-1] and t is not tickets[-2] else r["pcm_host"].numpy().copy(), r["kernel"]))
+    # collected results of captures whose slot was reused later are only checked through what was copied at collect
+    signs = [g[0] for g in got]
+    assert signs == [1, -1, 1, 1]
+    assert got[-1][2] == "k_channelize_mfma_s16_ring"
+    for idx in (2, 3):
+        want = O.run_chain(caps[idx], sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+        ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+        pcm = got[idx][1]
+        assert pcm.size == ref48.size == runner.n48
+        assert np.max(np.abs(pcm.astype(np.int32) - ref48.astype(np.int32))) <= 1
+    # the mis-speculated capture, alone: same answer as the oracle that is told nothing about the sign
+    t = runner.submit(devs[1])
+    r = runner.collect(t)
+    want = O.run_chain(caps[1], sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+    assert r["sign"] == want.mix_sign == -1
+    audio = r["audio"].cpu().numpy()
+    assert audio.size == want.audio.size and rms(audio - want.audio) < 2e-5
+    ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+    assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
+    assert abs(r["demod"].peak - want.audio_peak) < 1e-5
+
+
 def test_pipeline_cancel_removes_partial_output(A, tmp_path):
     """reference tests/test_processing.py:125-151: cancelling raises ProcessingCancelled and leaves no file."""
     from iq_to_audio_amd import iqio
