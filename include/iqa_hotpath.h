@@ -252,6 +252,11 @@ int iqa_resample(const void *x_dev, int64_t n_in, const void *table_dev, int32_t
 /* float32 -> PCM16 (round-half-even of y*32768, saturated).  Build-defined, see above. */
 int iqa_float_to_pcm16(const void *y_dev, int64_t n, void *pcm_dev, void *stream);
 
+/* Audio egress (the drain of AudioWriter, processing.py:433-438, without a host thread): copy nbytes from device
+ * memory into MAPPED pinned host memory (hipHostMalloc / torch pin_memory) with `workgroups` small workgroups
+ * (<= 0: 8), so that the copy can run beside a kernel that occupies every CU.  Both pointers 16-byte aligned. */
+int iqa_trickle_copy(const void *src_dev, void *dst_mapped, int64_t nbytes, int32_t workgroups, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -486,7 +486,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         const int64_t t_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q - col_shift + (full_tiles - 1) * 32 : t_last;
         if (t_last * D + 1 - consumed + slot_frames > n_frames || t_full * D + 1 - consumed + slot_frames > n_frames)
             return fail_inval("ring kernel range reads outside the block (use iqa_channelize for the edges)");
-        lds = mfma_ring_lds_bytes(ksteps) + 2 * acc_len * sizeof(int);  // one int32 (256*S1 + S2) per output component
+        lds = mfma_ring_lds_bytes(ksteps);  // ring + sliding window: independent of outputs_per_block
     }
     if (lds > 160 * 1024) return fail_inval("tap fragments + accumulators exceed 160 KiB of LDS");
 
@@ -517,11 +517,11 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     a.sc_re = p->out_scale_re;
     a.sc_im = p->out_scale_im;
     {
-        // rotation between outputs 256 apart, for the ring kernel's recurrence: frac(256*rot_step / 2^64) turns
-        const unsigned long long st = p->rot_step * 256ULL;
+        // rotation between outputs 64 apart, for the ring kernel's recurrence: frac(64*rot_step / 2^64) turns
+        const unsigned long long st = p->rot_step * 64ULL;
         const double turns = static_cast<double>(st >> 11) * (1.0 / 9007199254740992.0);
-        a.rotd_re = std::cos(2.0 * M_PI * turns);
-        a.rotd_im = std::sin(2.0 * M_PI * turns);
+        a.rot64_re = std::cos(2.0 * M_PI * turns);
+        a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
     if (ring) {
         mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream));

@@ -13,9 +13,14 @@
 //     cp = column-tile parity.  A round = two column tiles (cp 0/1); the four waves of a parity read the
 //     same slot (ds_read_b128 at row stride 4*D) and each multiplies it with ITS 32 tap rows, whose
 //     fragments (8*KS registers) stay in registers for the whole block -- no tap traffic through LDS;
-//   * ring of R rounds: the DMAs of round r+R-1 are issued during round r, one per k step, by two waves
-//     of each parity (one issuing wave per SIMD), behind a counted s_waitcnt vmcnt; one s_barrier per
-//     round publishes the landed slots and frees the oldest.
+//   * ring of R rounds (as many as LDS holds, <= 5): the DMAs of round r+R-1 are issued during round r, one
+//     per k step, by two waves of each parity (one issuing wave per SIMD), behind a counted s_waitcnt vmcnt;
+//     one s_barrier per round publishes the landed slots and frees the oldest;
+//   * the sums live in a 512-position sliding window (one int32 = 256*S1 + S2 per component): a round's
+//     scatter reaches 127 positions ahead, the 64 outputs completed two rounds ago are converted, rotated
+//     and stored by one wave while the others multiply, and their slots are reused 8 rounds later.  So a
+//     block is not bounded by LDS: every CU gets ONE contiguous range of the launch (persistent blocks:
+//     one prologue per CU, 63 rows of halo per CU).
 //
 // A slot is 2048*KS bytes >= 31 rows + one K-padded row (KS = ceil(2D/32) k steps), so an issuing wave
 // issues exactly KS DMAs per round.  Needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
@@ -29,28 +34,161 @@ namespace iqa {
 typedef __attribute__((address_space(3))) void ring_lds_t;
 
 constexpr int RG_WAVES = 8;
-constexpr int RG_THREADS = RG_WAVES * kWave;
+
 constexpr int RG_MAX_KS = 16;
+constexpr int RG_W = 512;      // sliding window of output sums (positions mod 512), per component
+constexpr int RG_GUARD = 64;   // a tile's scatter reaches at most 59 positions past its lane base: aliases of slots 0..63
+constexpr int RG_AS = RG_W + RG_GUARD;
+constexpr int RG_ACC_BYTES = 2 * RG_AS * 4;
+constexpr int RG_EMIT_WAVE = 2;  // (rt 2, parity 0): not an issuing wave
 
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void *)p));
 }
 
-__host__ __device__ constexpr int ring_rounds(int ks) { return ks <= 8 ? 3 : 2; }
+// rounds of two tiles the ring holds: as many as fit beside the 4.5 KiB window, at most 5 (vmcnt literals below)
+__host__ __device__ constexpr int ring_rounds(int ks)
+{
+    const int fit = (160 * 1024 - RG_ACC_BYTES) / (2 * 2048 * ks);
+    return fit > 5 ? 5 : (fit < 2 ? 2 : fit);
+}
 
 struct RingCtx {
     char *smem;
-    int *s_acc;
+    int *s_acc;           // [Sre | Sim], RG_AS ints each: S = 256*S1 + S2 of output position p at slot p mod RG_W
     const char *stream0;  // this lane's source byte of chunk (rt & 1) of tile 0
-    long long tile_bytes;
-    int tiles, rounds, acc_len, lane_off, rt, cp, col, h;
+    long long tile_bytes, i0, m0;
+    int tiles, rounds, cnt, lane_off, rt, cp, col, h, lane;
 };
 
-// The main loop of one wave.  ISSUER: this wave feeds the ring (chunks 2i + (rt & 1) of its parity's slot).
+// Emission state of the emitting wave: lane l owns position 64 k + 1 + l of group k; its rotation advances by
+// the host-computed step of 64 outputs per group (float64 recurrence, ~1e-16 per step).
+struct RingEmit {
+    double wc, ws;
+};
+
+__device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx &c, RingEmit &e, int k)
+{
+    const int pos = 64 * k + 1 + c.lane;
+    const int i = pos - MF_Q;  // output index inside the block
+    const int s = pos & (RG_W - 1);
+    int *acc = c.s_acc;
+    int sr = acc[s], si = acc[RG_AS + s];
+    if (s < RG_GUARD) {
+        sr += acc[RG_W + s];
+        si += acc[RG_AS + RG_W + s];
+        acc[RG_W + s] = 0;
+        acc[RG_AS + RG_W + s] = 0;
+    }
+    acc[s] = 0;  // the slot is scattered into again 8 rounds from now
+    acc[RG_AS + s] = 0;
+    if (i >= 0 && i < c.cnt) {
+        double d_re = (static_cast<double>(sr) * 256.0 + a.c_re) * a.unit;
+        double d_im = (static_cast<double>(si) * 256.0 + a.c_im) * a.unit;
+        if (a.partial_in != nullptr) {
+            const double2 pr = a.partial_in[c.i0 + i];
+            d_re += pr.x;
+            d_im += pr.y;
+        }
+        if (!a.finalize) {
+            a.partial_out[c.i0 + i] = make_double2(d_re, d_im);
+        } else {
+            float my_re = static_cast<float>(d_re);
+            float my_im = static_cast<float>(d_im);
+            if (a.conj_sum) my_im = -my_im;
+            float yr = my_re, yi = my_im;
+            if (a.rotate) {
+                const float cf = static_cast<float>(e.wc), sf = static_cast<float>(e.ws);
+                yr = my_re * cf - my_im * sf;
+                yi = my_re * sf + my_im * cf;
+            }
+            a.out[c.i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+        }
+    }
+    const double nc = e.wc * a.rot64_re - e.ws * a.rot64_im;
+    e.ws = fma(e.wc, a.rot64_im, e.ws * a.rot64_re);
+    e.wc = nc;
+}
+
+// LOADERS: the block has two extra waves (one per column parity) that do nothing but feed the ring and emit
+// finished outputs, and the eight multiplying waves never touch a DMA.  Used when the kernel fits 168 registers
+// (three waves on two of the SIMDs); otherwise (long rows) two multiplying waves per parity issue the DMAs and
+// wave RG_EMIT_WAVE emits.
+__host__ __device__ constexpr bool ring_has_loaders(int ks) { return ks <= 8; }
+
+template <int KS>
+__device__ __forceinline__ void ring_wait_and_barrier(int younger, int per_round)
+{
+    // an issuing wave's DMAs of round r have landed once only those of the younger rounds are outstanding
+    constexpr int R = ring_rounds(KS);
+    (void)per_round;
+    constexpr int N = ring_has_loaders(KS) ? 2 * KS : KS;  // DMAs per issuing wave and round
+    if (R >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * N) : "memory");
+    else if (R >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * N) : "memory");
+    else if (R >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    static_assert(3 * N <= 63 || R < 5, "vmcnt is a 6-bit counter");
+}
+
+// A loader wave (parity cp): per round, wait for its DMAs of this round, join the barrier, refill the slot the
+// previous round has left with the tile R-1 rounds ahead (all 2*KS chunks), and emit the group of 64 outputs that
+// became complete two rounds ago when that group's parity is its own.
+template <int KS, int DBG>
+__device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
+{
+    constexpr int R = ring_rounds(KS);
+    constexpr int SLOT = 2048 * KS;
+    constexpr bool STREAM = !(DBG & 16);
+    const int cp = c.cp;
+    auto issue_tile = [&](int tile, int slot) {
+        const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
+        char *dst = c.smem + (slot * 2 + cp) * SLOT;
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i)
+            __builtin_amdgcn_global_load_lds(src + i * 1024, (ring_lds_t *)(dst + i * 1024), 16, 0, 0);
+    };
+    if (STREAM) {
+#pragma unroll
+        for (int rr = 0; rr < R - 1; ++rr) issue_tile(2 * rr + cp, rr);
+    }
+    RingEmit em{1.0, 0.0};
+    double st_re = a.rot64_re * a.rot64_re - a.rot64_im * a.rot64_im, st_im = 2.0 * a.rot64_re * a.rot64_im;  // 128 outputs
+    if (a.finalize && a.rotate) {
+        const unsigned long long m = static_cast<unsigned long long>(c.m0 + (64 * cp + 1 + c.lane - MF_Q));  // group cp
+        const unsigned long long ph = a.rot_base + m * a.rot_step;
+        sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &em.ws, &em.wc);
+    }
+    MfmaArgs a2 = a;  // ring_emit_group advances the rotation by (rot64_re, rot64_im): this wave owns every other group
+    a2.rot64_re = st_re;
+    a2.rot64_im = st_im;
+    int slot = 0;
+    for (int r = 0; r < c.rounds; ++r) {
+        if (STREAM) ring_wait_and_barrier<KS>(min(R - 2, c.rounds - 1 - r), 0);
+        else asm volatile("s_barrier" ::: "memory");
+        if (STREAM && r + R - 1 < c.rounds) issue_tile(2 * (r + R - 1) + cp, (slot == 0) ? R - 1 : slot - 1);
+        if (r >= 2 && ((r - 2) & 1) == cp) {
+            // every wave has ISSUED its LDS adds of round r-1 before this barrier; a wave has at most 15 LDS
+            // operations outstanding and they complete in order, so all adds of round r-2 and earlier -- everything
+            // that reaches positions <= 64 (r-1) -- have landed.
+            asm volatile("" ::: "memory");
+            ring_emit_group(a2, c, em, r - 2);
+            asm volatile("" ::: "memory");
+        }
+        slot = (slot + 1 == R) ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int k_last = (c.cnt + 62) >> 6;
+    for (int k = max(c.rounds - 2, 0); k <= k_last; ++k)
+        if ((k & 1) == cp) ring_emit_group(a2, c, em, k);
+}
+
+// The main loop of a multiplying wave.  ISSUER (kernels without loader waves): this wave also feeds the ring
+// (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
+// outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ISSUER>
-__device__ __forceinline__ void ring_main(const RingCtx &c, const v4i_t (&fq)[KS][2])
+template <int KS, int DBG, bool ISSUER, bool EMIT>
+__device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
 {
     constexpr int R = ring_rounds(KS);
     constexpr int SLOT = 2048 * KS;
@@ -67,19 +205,21 @@ __device__ __forceinline__ void ring_main(const RingCtx &c, const v4i_t (&fq)[KS
 #pragma unroll
             for (int i = 0; i < KS; ++i) issue(2 * rr + cp, rr, i);
     }
+    RingEmit em{1.0, 0.0};
+    if (EMIT && a.finalize && a.rotate) {
+        const unsigned long long m = static_cast<unsigned long long>(c.m0 + (1 + c.lane - MF_Q));  // group 0
+        const unsigned long long ph = a.rot_base + m * a.rot_step;
+        sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &em.ws, &em.wc);
+    }
     const v16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int slot = 0;
     for (int r = 0; r < c.rounds; ++r) {
-        // an issuing wave's DMAs of round r have landed once only those of the younger rounds are outstanding
-        const int younger = min(R - 2, c.rounds - 1 - r);
-        if (!STREAM) {
-            asm volatile("s_barrier" ::: "memory");
-        } else if (R >= 4 && younger == 2) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * KS) : "memory");
-        } else if (R >= 3 && younger == 1) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KS) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (STREAM) ring_wait_and_barrier<KS>(min(R - 2, c.rounds - 1 - r), 0);
+        else asm volatile("s_barrier" ::: "memory");
+        if (EMIT && r >= 2) {
+            asm volatile("" ::: "memory");
+            ring_emit_group(a, c, em, r - 2);  // see ring_loader for why these sums are final
+            asm volatile("" ::: "memory");
         }
         const bool pf = STREAM && (r + R - 1 < c.rounds);
         const int pf_tile = 2 * (r + R - 1) + cp;
@@ -130,12 +270,12 @@ __device__ __forceinline__ void ring_main(const RingCtx &c, const v4i_t (&fq)[KS
                 if (DBG & 1) {
                     asm volatile("" ::"v"(acc1), "v"(acc2));
                 } else {
-                    // diagonal scatter into the block's sums (row = q, column = data row: output = row + column).
+                    // diagonal scatter into the window of sums (row = q, column = data row: output = row + column).
                     // Written as inline asm on purpose: the compiler drains vmcnt to 0 before any LDS store it can see
-                    // while LDS-DMAs are in flight (it cannot tell the ring from the accumulators), which would serialise
-                    // the whole prefetch pipeline once per round.  These adds touch s_acc only, never the ring.
-                    const unsigned p =
-                        lds_addr(c.s_acc + (t * 32 + c.col + 4 * c.h + 1) + (rt >> 1) * c.acc_len + (rt & 1) * 32);
+                    // while LDS-DMAs are in flight (it cannot tell the ring from the window), which would serialise
+                    // the whole prefetch pipeline once per round.  These adds touch the window only, never the ring.
+                    const unsigned p = lds_addr(c.s_acc + ((t * 32 + c.col + 4 * c.h + 1) & (RG_W - 1)) + (rt >> 1) * RG_AS +
+                                                (rt & 1) * 32);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         // 256*S1 + S2 in ONE int32 (the host bounds the tap magnitudes so that this cannot overflow for
@@ -155,35 +295,63 @@ __device__ __forceinline__ void ring_main(const RingCtx &c, const v4i_t (&fq)[KS
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
+    // the last groups: everything has landed behind a full wait and one more barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (EMIT) {
+        const int k_last = (c.cnt + 62) >> 6;
+        for (int k = max(c.rounds - 2, 0); k <= k_last; ++k) ring_emit_group(a, c, em, k);
+    }
 }
 
+template <int KS>
+constexpr int ring_threads() { return (RG_WAVES + (ring_has_loaders(KS) ? 2 : 0)) * kWave; }
+
+// One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
+// stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
 template <int KS, int DBG>
-__global__ __launch_bounds__(RG_THREADS, 2) void k_channelize_mfma_s16_ring(MfmaArgs a)
+__global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) void k_channelize_mfma_s16_ring(MfmaArgs a)
 {
     constexpr int R = ring_rounds(KS);
     constexpr int SLOT = 2048 * KS;
+    constexpr bool LOADERS = ring_has_loaders(KS);
+    static_assert(R * 2 * SLOT + RG_ACC_BYTES <= 160 * 1024, "ring + window exceed LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     RingCtx c;
+    c.lane = tid & 63;
     c.rt = wave & 3;
-    c.cp = wave >> 2;
-    c.col = lane & 31;
-    c.h = lane >> 5;
+    c.cp = (wave >> 2) & 1;
+    c.col = c.lane & 31;
+    c.h = c.lane >> 5;
 
-    const long long i0 = static_cast<long long>(blockIdx.x) * a.range;
-    const int cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - i0));
-    const long long m0 = a.m_lo + i0;
-    c.tiles = (cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
-    c.acc_len = c.tiles * 32 + MF_Q + 4;
+    c.i0 = static_cast<long long>(blockIdx.x) * a.range;
+    c.cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - c.i0));
+    c.m0 = a.m_lo + c.i0;
+    c.tiles = (c.cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
     c.rounds = (c.tiles + 1) >> 1;
     c.smem = smem;
-    c.s_acc = reinterpret_cast<int *>(smem + R * 2 * SLOT);  // [Sre | Sim], acc_len ints each, S = 256*S1 + S2
+    c.s_acc = reinterpret_cast<int *>(smem + R * 2 * SLOT);
+    for (int i = tid; i < 2 * RG_AS; i += ring_threads<KS>()) c.s_acc[i] = 0;
 
+    // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
+    const long long row_bytes = 4LL * a.D;
+    c.tile_bytes = 32 * row_bytes;
+    const char *stream = reinterpret_cast<const char *>(a.raw) + 4 * ((c.m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
+                         c.lane * 16;
+    c.lane_off = c.col * static_cast<int>(row_bytes) + 32 * c.h;
+
+    if (LOADERS && wave >= RG_WAVES) {
+        c.cp = wave - RG_WAVES;
+        c.stream0 = stream;
+        __syncthreads();
+        ring_loader<KS, DBG>(a, c);
+        return;
+    }
     // tap fragments of this wave's row tile: registers for the whole block
     v4i_t fq[KS][2];
     {
-        const v4i_t *fa = a.afrag + c.rt * 128 + lane;
+        const v4i_t *fa = a.afrag + c.rt * 128 + c.lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -192,26 +360,13 @@ __global__ __launch_bounds__(RG_THREADS, 2) void k_channelize_mfma_s16_ring(Mfma
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(fq[ks][0]), "v"(fq[ks][1]));
     }
-    {
-        v4i_t *z = reinterpret_cast<v4i_t *>(c.s_acc);
-        for (int i = tid; i < c.acc_len / 2; i += RG_THREADS) z[i] = v4i_t{0, 0, 0, 0};  // 2*acc_len ints, acc_len % 4 == 0
-    }
     __syncthreads();
-
-    // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
-    const long long row_bytes = 4LL * a.D;
-    c.tile_bytes = 32 * row_bytes;
-    c.stream0 = reinterpret_cast<const char *>(a.raw) + 4 * ((m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
-                lane * 16 + (c.rt & 1) * 1024;
-    c.lane_off = c.col * static_cast<int>(row_bytes) + 32 * c.h;
-
+    c.stream0 = stream + (c.rt & 1) * 1024;
+    if (LOADERS) ring_main<KS, DBG, false, false>(a, c, fq);
     // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
-    if ((c.rt >> 1) == c.cp) ring_main<KS, DBG, true>(c, fq);
-    else ring_main<KS, DBG, false>(c, fq);
-
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the asm ds_add are invisible to the compiler's counters
-    __syncthreads();
-    mfma_emit_rec<RG_THREADS>(a, c.s_acc, c.acc_len, cnt, i0, m0, tid);
+    else if ((c.rt >> 1) == c.cp) ring_main<KS, DBG, true, false>(a, c, fq);
+    else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, false, true>(a, c, fq);
+    else ring_main<KS, DBG, false, false>(a, c, fq);
 }
 
 bool mfma_ring_supported(int decimation)
@@ -220,7 +375,7 @@ bool mfma_ring_supported(int decimation)
     return decimation >= 4 && (decimation & 3) == 0 && ks <= RG_MAX_KS;
 }
 
-size_t mfma_ring_lds_bytes(int ksteps) { return static_cast<size_t>(ring_rounds(ksteps)) * 2 * 2048 * ksteps; }
+size_t mfma_ring_lds_bytes(int ksteps) { return static_cast<size_t>(ring_rounds(ksteps)) * 2 * 2048 * ksteps + RG_ACC_BYTES; }
 
 template <int KS, int DBG>
 static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
@@ -231,7 +386,7 @@ static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipS
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_channelize_mfma_s16_ring<KS, DBG>), dim3(blocks), dim3(RG_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((k_channelize_mfma_s16_ring<KS, DBG>), dim3(blocks), dim3(ring_threads<KS>()), lds, stream, a);
 }
 
 void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)

@@ -333,7 +333,7 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 // cross-lane reduction is 4 butterfly steps per 4 outputs.  Input windows are read as
 // contiguous 16-float runs; the table is read once in total.
 constexpr int RS_WAVES = 4;
-constexpr int RS_MAX_NI = 12;  // rows up to 192 taps
+
 template <int NI>  // taps per lane = ceil(row_len / 16)
 __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
                                                                int down, int T, long long j0, long long n_out, float *y,

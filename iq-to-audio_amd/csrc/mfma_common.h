@@ -33,7 +33,7 @@ struct MfmaArgs {
     int conj_sum, rotate;
     unsigned long long rot_step, rot_base;
     float sc_re, sc_im;
-    double rotd_re, rotd_im;  // exp(j*2*pi*256*rot_step): rotation between outputs 256 apart (ring kernel emission)
+    double rot64_re, rot64_im;  // exp(j*2*pi*64*rot_step): rotation between outputs 64 apart (ring kernel emission)
 };
 
 // emission shared by both kernels: output m0+i sits at position 64+i of the S1/S2 arrays
@@ -74,58 +74,9 @@ __device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, i
     }
 }
 
-// Emission of the ring kernel: the same arithmetic as mfma_emit, but the float64 sincospi is evaluated once
-// per thread; the outputs a thread owns are THREADS (256 or 512) apart, so their rotations follow from a
-// float64 complex recurrence with the host-computed step (error ~1e-16 per step, far below the float32
-// rounding the rotation is applied in).
-template <int THREADS>
-__device__ __forceinline__ void mfma_emit_rec(const MfmaArgs &a, const int *s_acc, int acc_len, int cnt, long long i0,
-                                              long long m0, int tid)
-{
-    static_assert(THREADS == 256 || THREADS == 512, "rotd is the step for 256 outputs");
-    const double st_re = THREADS == 256 ? a.rotd_re : a.rotd_re * a.rotd_re - a.rotd_im * a.rotd_im;
-    const double st_im = THREADS == 256 ? a.rotd_im : 2.0 * a.rotd_re * a.rotd_im;
-    double wc = 1.0, ws = 0.0;
-    if (a.finalize && a.rotate && tid < cnt) {
-        const unsigned long long m = static_cast<unsigned long long>(m0 + tid);
-        const unsigned long long ph = a.rot_base + m * a.rot_step;
-        const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
-        sincospi(2.0 * frac, &ws, &wc);
-    }
-    for (int i = tid; i < cnt; i += THREADS) {
-        const int pos = MF_Q + i;
-        // the ring kernel keeps S = 256*S1 + S2 per component in one int32
-        const double sr = s_acc[pos], si = s_acc[acc_len + pos];
-        double d_re = (sr * 256.0 + a.c_re) * a.unit;
-        double d_im = (si * 256.0 + a.c_im) * a.unit;
-        if (a.partial_in != nullptr) {
-            const double2 pr = a.partial_in[i0 + i];
-            d_re += pr.x;
-            d_im += pr.y;
-        }
-        if (!a.finalize) {
-            a.partial_out[i0 + i] = make_double2(d_re, d_im);
-            continue;
-        }
-        float my_re = static_cast<float>(d_re);
-        float my_im = static_cast<float>(d_im);
-        if (a.conj_sum) my_im = -my_im;
-        float yr = my_re, yi = my_im;
-        if (a.rotate) {
-            const float cf = static_cast<float>(wc), sf = static_cast<float>(ws);
-            yr = my_re * cf - my_im * sf;
-            yi = my_re * sf + my_im * cf;
-            const double nc = wc * st_re - ws * st_im;
-            ws = fma(wc, st_im, ws * st_re);
-            wc = nc;
-        }
-        a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
-    }
-}
-
 // launcher of the ring kernels (channelize_ring.hip); returns false when no instantiation covers `ksteps`
 bool mfma_ring_supported(int decimation);
-size_t mfma_ring_lds_bytes(int ksteps);  // LDS taken by the data ring (the S1/S2 accumulators follow it)
+size_t mfma_ring_lds_bytes(int ksteps);  // LDS of the ring kernel: data ring + the sliding window of sums
 void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds_bytes, hipStream_t stream);
 
 }  // namespace iqa

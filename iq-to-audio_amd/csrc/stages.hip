@@ -51,9 +51,37 @@ __global__ void k_oscillator_mix(const void *in, long long n, int iq_order, doub
     out[i] = make_float2(xr * cf - xi * sf, xr * sf + xi * cf);
 }
 
+// Audio egress without the runtime's blit kernel: hipMemcpyAsync D2H is a copy kernel that fills the GPU with
+// waves parked on PCIe stores, and a one-block-per-CU kernel launched beside it waits until they are gone.
+// A handful of workgroups writing 1 KiB per wave-instruction straight into mapped pinned host memory move the
+// few MB of PCM16 at the same PCIe rate while the channelizer of the next capture runs on all other CUs.
+__global__ __launch_bounds__(256) void k_trickle_copy(const uint4 *src, uint4 *dst, long long n16, const unsigned char *src_tail,
+                                                       unsigned char *dst_tail, int tail_bytes)
+{
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail_bytes) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 }  // namespace iqa
 
 using namespace iqa;
+
+extern "C" int iqa_trickle_copy(const void *src_dev, void *dst_mapped, int64_t nbytes, int32_t workgroups, void *stream)
+{
+    if (nbytes < 0) return fail_inval("negative length");
+    if (nbytes == 0) return IQA_OK;
+    if (!src_dev || !dst_mapped) return fail_inval("NULL pointer");
+    if ((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst_mapped)) & 15) return fail_inval("pointers must be 16-byte aligned");
+    if (workgroups < 1) workgroups = 8;
+    const int64_t n16 = nbytes / 16;
+    const int tail = static_cast<int>(nbytes - n16 * 16);
+    hipLaunchKernelGGL(k_trickle_copy, dim3(static_cast<unsigned>(workgroups)), dim3(256), 0, as_stream(stream),
+                       static_cast<const uint4 *>(src_dev), static_cast<uint4 *>(dst_mapped), (long long)n16,
+                       static_cast<const unsigned char *>(src_dev) + n16 * 16, static_cast<unsigned char *>(dst_mapped) + n16 * 16,
+                       tail);
+    return check_launch("k_trickle_copy");
+}
 
 extern "C" int iqa_abi_version(void) { return IQA_ABI_VERSION; }
 

@@ -202,18 +202,16 @@ class _ChannelKernel:
         return self.mfma
 
     def _range_max(self, k_count: int, variant: str) -> int:
-        if variant == "ring":  # tap fragments live in registers: LDS = data ring + accumulators
-            # capped at 6144 outputs: ring + 8 B/output then leaves >= 24 KiB of LDS per CU, so that the small kernels
-            # of another stream (demodulator scans, resampler, mixer-sign probes) can run beside the channelizer
-            lds = 160 * 1024 - self._ring_bytes
-            return int(min(6144, (lds // 8 - 160) // 32 * 32))
+        if variant == "ring":  # tap fragments in registers, sums in a sliding window: a block is not bounded by LDS
+            return 1 << 24
         lds = 160 * 1024 - k_count * P.MFMA_KSTEP_BYTES - self._VARIANT[variant][1]
         return int(min(6144, (lds // 16 - 160) // 32 * 32))
 
     @staticmethod
     def _block_outputs(n_out: int, rmax: int) -> int:
         """Outputs per block for a launch of ``n_out`` outputs: as large as LDS allows, but chosen so that the
-        number of blocks is a multiple of the 256 CUs (one block per CU, no ragged last round)."""
+        number of blocks is a multiple of the 256 CUs (one block per CU, no ragged last round).  The ring kernel
+        has no LDS bound (``rmax`` huge): every CU gets ONE contiguous range of the launch."""
         rounds = max(1, -(-n_out // (256 * rmax)))
         per = -(-n_out // (256 * rounds))
         return int(min(rmax, max(512, -(-per // 32) * 32)))
@@ -402,15 +400,16 @@ class Channelizer:
         m_end = -(-(self.consumed + n_frames) // d)
         return m_first, m_end - m_first
 
-    def process(self, raw, out_dev=None, events=None):
+    def process(self, raw, out_dev=None, events=None, last_block: bool = False):
         """``raw``: interleaved frames (NumPy or device tensor, dtype of ``fmt``; complex64 for f32).
-        Returns the decimated complex64 samples for this block."""
+        Returns the decimated complex64 samples for this block.  ``last_block``: nothing follows, so the
+        L-1 frame history is not carried over (saves a launch for whole-capture calls)."""
         x, n = _as_frames(raw, self.fmt)
         if n == 0:
             return D.like_input(D.empty(0, "complex64"), raw)
         m_first, n_out = self.outputs_for(n)
         z = self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events) if n_out else D.empty(0, "complex64")
-        keep = self.ntaps - 1
+        keep = 0 if last_block else self.ntaps - 1
         if keep:
             nxt = D.empty(keep * iqio.FRAME_BYTES[self.fmt], "uint8")
             N.call("iqa_history_update", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.ntaps), N.ptr(self._hist),
@@ -472,7 +471,7 @@ class MixSignProbe:
         for i, sign in enumerate((1, -1)):
             ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
                              fmt=fmt, iq_order=iq_order)
-            z = ch.process(x)
+            z = ch.process(x, last_block=True)
             if z.numel():
                 discard = min(ntaps, z.numel() // 4)
                 if z.numel() - discard == 0:
@@ -569,20 +568,56 @@ class ChannelDemod:
             dc_radius=0.995 if isinstance(d, NarrowbandFMDecoder) else d._dc_blocker.radius,
             agc_target=d._agc_level if is_ssb else 0.0, agc_decay=d._agc_decay if is_ssb else 0.0)
         self._needs_scratch = is_ssb and bool(agc_enabled)
-        state = np.zeros(8, dtype=np.float32)  # {float2 prev = 1+0j; double y_last; double x_last, y_last}
-        state[0] = 1.0
-        self.state_dev = D.from_numpy(state)
-        self.peak_dev = D.zeros(1, "float32")
-        self.chunk_sumsq: list = []  # (device float64[n_chunks], counts)
+        self.chunk_sumsq: list = []  # (device float64[n_chunks*8], counts)
+        self._blk = None  # one device block: [state 32 B | peak 4 B (+pad to 64) | sumsq n_chunks*8 f64]
+        self._starts_key = None
+        self._fresh = False
+        self._alloc_block(0)
+
+    # {float2 prev = 1+0j; double y_last; double x_last, y_last} -- the states of a decoder that has seen nothing
+    _STATE0 = np.array([1.0, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+
+    def _alloc_block(self, n_chunks: int) -> None:
+        torch = D.torch_mod()
+        img = np.zeros(64 + n_chunks * 64, dtype=np.uint8)
+        img[:32] = self._STATE0.view(np.uint8)
+        self._img, self._img_host = img, None
+        self._blk = D.from_numpy(img)
+        self._n_chunks = n_chunks
+        self.state_dev = self._blk[:32].view(torch.float32)
+        self.peak_dev = self._blk[32:36].view(torch.float32)
+        self._sumsq = self._blk[64:].view(torch.float64)
+        self._fresh = True
+
+    def reset(self) -> None:
+        """Back to a decoder that has seen nothing (states, peak, per-chunk sums): one small H2D copy from a
+        pinned image (pinned on the first reset: pin_memory() costs milliseconds)."""
+        self.chunk_sumsq = []
+        if self._fresh:
+            return
+        if self._img_host is None:
+            self._img_host = D.torch_mod().from_numpy(self._img).pin_memory()
+        self._blk.copy_(self._img_host, non_blocking=True)
+        self._fresh = True
 
     def prepare(self, n: int, chunk_starts: np.ndarray):
         """Upload / allocate everything ``process`` needs for a block of ``n`` samples ahead of time, so the
-        launches that follow a long kernel are not preceded by host-side copies."""
-        starts_dev = D.from_numpy(np.ascontiguousarray(chunk_starts, dtype=np.int64))
-        sumsq = D.zeros(len(chunk_starts) * 8, "float64")  # IQA_SUMSQ_SLOTS sub-slots per chunk
-        work = D.empty(int(N.lib().iqa_scan_workspace_bytes(n)), "uint8")
-        scratch = D.empty(n, "float32") if self._needs_scratch else None
-        self._prepared = (n, len(chunk_starts), starts_dev, sumsq, work, scratch)
+        launches that follow a long kernel are not preceded by host-side copies.  The chunk starts and the scan
+        workspace are kept while the block shape stays the same (a batch of equal captures uploads them once)."""
+        starts64 = np.ascontiguousarray(chunk_starts, dtype=np.int64)
+        key = (n, len(starts64), hash(starts64.tobytes()))
+        if key != self._starts_key:
+            self._starts_dev = D.from_numpy(starts64)
+            self._work = D.empty(int(N.lib().iqa_scan_workspace_bytes(n)), "uint8")
+            self._scratch = D.empty(n, "float32") if self._needs_scratch else None
+            self._starts_key = key
+        if self._fresh and not self.chunk_sumsq:
+            if len(starts64) != self._n_chunks:
+                self._alloc_block(len(starts64))  # nothing processed yet: the block is simply re-made at this size
+            sumsq = self._sumsq
+        else:  # later blocks of a streaming run: their own sums (all read back at the end)
+            sumsq = D.zeros(len(starts64) * 8, "float64")  # IQA_SUMSQ_SLOTS sub-slots per chunk
+        self._prepared = (n, len(starts64), self._starts_dev, sumsq, self._work, self._scratch)
 
     def process(self, z_dev, chunk_starts: np.ndarray, out_dev):
         """z_dev -> clipped float32 audio written into ``out_dev`` (len == len(z_dev))."""
@@ -594,6 +629,7 @@ class ChannelDemod:
             self.prepare(n, chunk_starts)
         _, _, starts_dev, sumsq, work, scratch = self._prepared
         self._prepared = None
+        self._fresh = False
         N.call("iqa_demodulate", byref(self.params), N.ptr(z_dev), c_int64(n), N.ptr(self.state_dev), N.ptr(starts_dev),
                c_int64(len(chunk_starts)), N.ptr(self.peak_dev), N.ptr(sumsq), N.ptr(out_dev), N.ptr(scratch), N.ptr(work),
                N.stream_ptr())
@@ -677,37 +713,66 @@ class ResidentCaptureRunner:
         self.tail = torch.cuda.Stream() if tail_stream else self.compute
         self.egress = torch.cuda.Stream()
         self.slots = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
-                           pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(), busy=None)
+                           pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(), busy=None,
+                           dem=ChannelDemod(demod_mode, self.fs_ch, deemph_us=deemph_us, agc_enabled=agc_enabled))
                       for _ in range(self.SLOTS)]
         self._next = 0
+        self._egress_pending = None  # ticket whose D2H has not been queued yet (see _flush_egress)
+        self.egress_workgroups = 8
 
     def _chain(self, raw_dev, slot, sign: int, events=None):
-        """Channelizer on the compute stream, then demod/resample/PCM16 on the tail stream, D2H on the egress stream."""
+        """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
         torch = D.torch_mod()
         chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
                            fmt=self.fmt, iq_order=self.iq_order)
         chan.plan_ahead()
-        dem = ChannelDemod(self.demod_args["mode"], self.fs_ch, deemph_us=self.demod_args["deemph_us"],
-                           agc_enabled=self.demod_args["agc_enabled"])
+        dem = slot["dem"]
         with torch.cuda.stream(self.tail):
+            dem.reset()
             dem.prepare(self.n_dec, self.starts)
-        chan.process(raw_dev, out_dev=slot["z"], events=events)
-        z_ready = torch.cuda.Event()
-        z_ready.record()
-        self.tail.wait_event(z_ready)
+        gate = torch.cuda.Event()
+        gate.record()  # compute stream: behind this capture's probes, in front of its channelizer
+        prev = self._egress_pending
+        chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True)
+        if prev is not None:
+            self._flush_egress(gate)  # the previous capture's D2H runs beside the channelizer, not beside the probes
+        if self.tail is not self.compute:
+            z_ready = torch.cuda.Event()
+            z_ready.record()
+            self.tail.wait_event(z_ready)
         with torch.cuda.stream(self.tail):
             dem.process(slot["z"], self.starts, slot["audio"])
             y48 = self.rs.process(slot["audio"])
             pcm = self.rs.to_pcm16(y48)
             tail_done = torch.cuda.Event()
             tail_done.record()
-        self.egress.wait_event(tail_done)
+        done = torch.cuda.Event()
+        ticket = dict(chan=chan, dem=dem, pcm=pcm, y48=y48, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel,
+                      slot=slot, egress_queued=False)
+        self._egress_pending = ticket
+        return ticket
+
+    def _flush_egress(self, gate=None) -> None:
+        """Queue the D2H of the capture whose PCM16 is ready (or will be, behind its tail_done event).  Called right
+        before the next capture's channelizer is launched, gated on an event behind that capture's probes, so the
+        copy kernel -- whose waves sit on PCIe stores -- shares the GPU with the long HBM-bound kernel instead of the
+        small latency-bound ones (measured: a probe beside the copy takes 120 us instead of 20); from ``collect``,
+        ungated, for the last capture of a batch."""
+        t = self._egress_pending
+        if t is None or t["egress_queued"]:
+            return
+        torch = D.torch_mod()
+        self.egress.wait_event(t["tail_done"])
+        if gate is not None:
+            self.egress.wait_event(gate)
         with torch.cuda.stream(self.egress):
-            pcm.record_stream(self.egress)
-            slot["pcm_host"].copy_(pcm, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
-        return dict(chan=chan, dem=dem, pcm=pcm, y48=y48, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel)
+            t["pcm"].record_stream(self.egress)
+            host = t["slot"]["pcm_host"]
+            N.call("iqa_trickle_copy", N.ptr(t["pcm"]), c_void_p(host.data_ptr()), c_int64(host.numel() * host.element_size()),
+                   c_int32(self.egress_workgroups), N.stream_ptr())
+            t["done"].record()
+        t["egress_queued"] = True
+        self._egress_pending = None
 
     def submit(self, raw_dev, events=None) -> dict:
         """Queue one capture (device tensor of interleaved frames, ``n_frames`` long).  Returns a ticket for ``collect``."""
@@ -720,8 +785,6 @@ class ResidentCaptureRunner:
             torch.cuda.current_stream().wait_event(slot["tail_done"])  # z/audio of this slot are free again
         probe = None
         if self.override is None:
-            # the probes only read the capture: they run on the tail stream, beside the previous capture's
-            # channelizer, and the compute stream carries nothing but channelizers
             warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
             ready = torch.cuda.Event()
             ready.record()
@@ -731,7 +794,7 @@ class ResidentCaptureRunner:
         sign = self.override if self.override is not None else 1
         ticket = self._chain(raw_dev, slot, sign, events)
         slot["tail_done"] = ticket["tail_done"]
-        ticket.update(slot=slot, probe=probe, sign=sign, raw=raw_dev)
+        ticket.update(probe=probe, sign=sign, raw=raw_dev)
         slot["busy"] = ticket
         return ticket
 
@@ -742,13 +805,17 @@ class ResidentCaptureRunner:
         if ticket.get("collected"):
             return ticket["result"]
         sign = ticket["sign"]
+        if self._egress_pending is ticket:
+            self._flush_egress()
         if ticket["probe"] is not None:
             sign = ticket["probe"].result()
             if sign != ticket["sign"]:  # the speculation was wrong: this capture again, with the sign the probe chose
                 ticket["done"].synchronize()
-                redo = self._chain(ticket["raw"], slot, sign)
+                probe, raw = ticket["probe"], ticket["raw"]
+                redo = self._chain(raw, slot, sign)
+                self._flush_egress()
                 slot["tail_done"] = redo["tail_done"]
-                ticket.update(redo, sign=sign)
+                ticket.update(redo, sign=sign, probe=probe, raw=raw)
         ticket["done"].synchronize()
         ticket["collected"] = True
         ticket["raw"] = ticket["pcm"] = ticket["y48"] = None  # back to the allocator: the next capture reuses them
