@@ -107,9 +107,11 @@ def main() -> None:
         t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]))
         tickets.append(t)
         if world > 1:
-            with torch.cuda.stream(runner.egress):  # behind this capture's D2H, overlapping the next capture's kernels
+            runner.egress.wait_event(t["tail_done"])  # this capture's PCM16 is complete
+            with torch.cuda.stream(runner.egress):    # the gather overlaps the next capture's kernels
                 while pending:
                     pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
+                t["pcm"].record_stream(runner.egress)
                 pending.append(dist.gather(t["pcm"].view(torch.uint8), gathered, dst=0, async_op=True))
         return t
 

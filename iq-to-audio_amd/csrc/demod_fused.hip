@@ -145,25 +145,42 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_reduce(FusedArgs a)
     }
 }
 
+// Carry pass: exclusive scan of the per-tile maps.  One block of 1024 threads: a thread composes its run of
+// consecutive tiles, a wave scan and a 16-entry table in LDS give it the state in front of its run, and it walks
+// the run once more to store the carries (a single wave walking thousands of tiles serially cost 30 us).
+constexpr int FC_THREADS = 1024;
 template <int OP>
-__global__ __launch_bounds__(kWave) void k_fused_carry(FusedArgs a)
+__global__ __launch_bounds__(FC_THREADS) void k_fused_carry(FusedArgs a)
 {
-    const int lane = threadIdx.x;
-    double s;
-    if constexpr (OP == F_DEEMPH) s = a.st[0];
-    else if constexpr (OP == F_DC) s = a.st[1];
-    else s = 1.0;
-    for (int c = 0; c < a.nblocks; c += kWave) {
-        const int b = c + lane;
-        const Aff v = (b < a.nblocks) ? a.agg[b] : Aff{1.0, 0.0};
-        const Aff inc = wave_inclusive(v, lane);
-        const double after = fma(inc.A, s, inc.B);
-        double before = __shfl_up(after, 1, kWave);
-        if (lane == 0) before = s;
-        if (b < a.nblocks) a.carry[b] = before;
-        s = __shfl(after, kWave - 1, kWave);
+    __shared__ Aff s_w[FC_THREADS / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s0;
+    if constexpr (OP == F_DEEMPH) s0 = a.st[0];
+    else if constexpr (OP == F_DC) s0 = a.st[1];
+    else s0 = 1.0;
+    const int per = (a.nblocks + FC_THREADS - 1) / FC_THREADS;
+    const int b0 = tid * per;
+    Aff t{1.0, 0.0};
+    for (int i = 0; i < per; ++i)
+        if (b0 + i < a.nblocks) t = then(t, a.agg[b0 + i]);
+    const Aff inc = wave_inclusive(t, lane);
+    if (lane == kWave - 1) s_w[wave] = inc;
+    __syncthreads();
+    Aff pre{1.0, 0.0};
+    for (int w = 0; w < wave; ++w) pre = then(pre, s_w[w]);
+    Aff exl{__shfl_up(inc.A, 1, kWave), __shfl_up(inc.B, 1, kWave)};
+    if (lane == 0) exl = Aff{1.0, 0.0};
+    const Aff ex = then(pre, exl);
+    double s = fma(ex.A, s0, ex.B);  // state in front of this thread's run
+    for (int i = 0; i < per; ++i) {
+        const int b = b0 + i;
+        if (b < a.nblocks) {
+            a.carry[b] = s;
+            const Aff v = a.agg[b];
+            s = fma(v.A, s, v.B);
+        }
     }
-    if (lane == 0) a.fin[0] = s;
+    if (tid == FC_THREADS - 1) a.fin[0] = s;  // runs past the end are identity maps: the last thread holds the total
 }
 
 template <int OP, int SRC, int SINK>
@@ -277,7 +294,7 @@ static int launch_fused(FusedArgs a, float2 *prev_out, double *st_out, void *wor
     a.carry = reinterpret_cast<double *>(w + sizeof(Aff) * a.nblocks);
     a.fin = a.carry + a.nblocks;
     hipLaunchKernelGGL((k_fused_reduce<OP, SRC>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, a);
-    hipLaunchKernelGGL((k_fused_carry<OP>), dim3(1), dim3(kWave), 0, s, a);
+    hipLaunchKernelGGL((k_fused_carry<OP>), dim3(1), dim3(FC_THREADS), 0, s, a);
     hipLaunchKernelGGL((k_fused_apply<OP, SRC, SINK>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, a);
     if (OP != F_AGC) hipLaunchKernelGGL((k_fused_finish<OP, SRC>), dim3(1), dim3(1), 0, s, a, prev_out, st_out);
     return check_launch("fused demodulator");
