@@ -257,6 +257,27 @@ int iqa_float_to_pcm16(const void *y_dev, int64_t n, void *pcm_dev, void *stream
  * (<= 0: 8), so that the copy can run beside a kernel that occupies every CU.  Both pointers 16-byte aligned. */
 int iqa_trickle_copy(const void *src_dev, void *dst_mapped, int64_t nbytes, int32_t workgroups, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * Spectrum / waterfall                                   *
+ * ------------------------------------------------------------------------- */
+
+/* ref: spectrum.py _SlidingFFT.psd :143-171, compute_psd :15-45, the frame loop of streaming_waterfall :58-93.
+ * For f in [0, n_frames): frame = samples[first + f*hop : ... + use] (fmt / iq_order as in iqa_oscillator_mix),
+ *   X = FFT_nfft(complex128(frame) * window[0:use], zero-padded to nfft)          (rocFFT, double complex)
+ *   psd_db[f][k] = 10*log10(|X[(k - nfft/2) mod nfft]|^2 / scale + 1e-18)           (fftshift-ed, dB)
+ * window_dev = double[use] (np.hanning(use)); scale = use*sample_rate*win_power + 1e-18 (spectrum.py:39,167).
+ * work_dev = double2[n_frames*nfft] scratch.  Outputs, each optional (NULL): psd_db_dev double[n_frames][nfft],
+ * psd_db_f32_dev float[n_frames][nfft] (the waterfall's slices, spectrum.py:181), sum_db_dev double[nfft]
+ * += sum over the batch's frames (the averaged PSD accumulates dB values, spectrum.py:79-82).
+ * FFT plans are cached inside the library per (nfft, n_frames). */
+int iqa_psd_frames(int32_t fmt, int32_t iq_order, const void *samples_dev, int64_t n_samples, int64_t first,
+                   int64_t hop, int32_t n_frames, int32_t nfft, int32_t use, const void *window_dev, double scale,
+                   void *work_dev, void *psd_db_dev, void *psd_db_f32_dev, void *sum_db_dev, void *stream);
+
+/* ref: _WaterfallAggregator._maybe_reduce, spectrum.py:190-208.  out[r] = float32((double(in[2r]) + double(in[2r+1]))/2),
+ * an odd last row is copied; out_dev (ceil(n_rows/2) rows) must not alias rows_dev. */
+int iqa_pair_average_rows(const void *rows_dev, int32_t n_rows, int32_t n_cols, void *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -657,6 +657,105 @@ def float_to_pcm16(y: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(y.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
 
 
+# --------------------------------------------------------------------------- #
+# spectrum / waterfall -- parity PINNED by tests/golden/spectrum.npz,   #
+# generated from the reference's own functions by oracle/gen_golden_spectrum.py            #
+# --------------------------------------------------------------------------- #
+
+PSD_FLOOR = 1e-18
+
+
+def psd_frame_db(frame: np.ndarray, nfft: int, sample_rate: float) -> np.ndarray:
+    """One fftshift-ed PSD frame in dB.  spectrum.py:29-44 (compute_psd) == :156-171 (_SlidingFFT.psd):
+    Hann window of the frame's own length n, complex128 FFT zero-padded to nfft,
+    |X|^2 / (n * fs * mean(w^2) + 1e-18), 10*log10(. + 1e-18)."""
+    n = frame.size
+    w = np.hanning(n).astype(np.float64)
+    scale = n * sample_rate * (np.sum(w * w) / n) + PSD_FLOOR
+    spec = np.fft.fftshift(_sfft.fft(frame.astype(np.complex128) * w, n=nfft))
+    power = (spec.real * spec.real + spec.imag * spec.imag) / scale
+    return (10.0 * np.log10(np.abs(power) + PSD_FLOOR)).astype(np.float64)
+
+
+def psd_freqs(nfft: int, sample_rate: float) -> np.ndarray:
+    """spectrum.py:38-41, :152."""
+    return np.fft.fftshift(np.fft.fftfreq(nfft, d=1.0 / sample_rate)).astype(np.float64)
+
+
+def compute_psd(samples: np.ndarray, sample_rate: float, nfft: int = 1 << 18):
+    """spectrum.py:15-45: PSD of the first nfft samples (all of them, zero-padded, if fewer)."""
+    x = np.asarray(samples)
+    if x.size == 0:
+        raise ValueError("Cannot compute PSD for an empty signal.")
+    return psd_freqs(nfft, sample_rate), psd_frame_db(x[:nfft], nfft, sample_rate)
+
+
+def sliding_window_starts(block_sizes, nfft: int, hop: int):
+    """Every window the reference's iterator yields (spectrum.py:96-130) for blocks of the given sizes: windows of
+    nfft every hop over (carry + block), the unconsumed tail carried to the next block, no trailing partial window.
+    Returns [(reported_start, true_start)]: ``true_start`` is the window's position in the concatenated stream;
+    ``reported_start`` is the index the reference hands on (its ``offset`` is decremented by the carry length
+    although it already points at the carry, :110-111 with :125-126, so time stamps after a block boundary lag
+    by that many samples) -- reproduced because the waterfall's ``times`` are derived from it."""
+    out, carry, offset, consumed = [], 0, 0, 0
+    for size in block_sizes:
+        if size == 0:
+            continue
+        total = carry + size
+        base = consumed - carry  # true stream position of (carry + block)[0]
+        consumed += size
+        offset -= carry
+        if total < nfft:
+            carry = total
+            offset += total
+            continue
+        start = 0
+        while start + nfft <= total:
+            out.append((offset + start, base + start))
+            start += hop
+        tail = max(total - start, 0)
+        offset += total - tail
+        carry = min(tail, nfft)
+    return out
+
+
+def waterfall_reduce(slices: list, times: list, max_slices: int):
+    """spectrum.py:190-208: while more than max_slices rows, average neighbours pairwise in float64 (rounded back
+    to float32), keep an odd last row, keep the first time stamp of every pair."""
+    while len(slices) > max_slices:
+        nxt, nt = [], []
+        for i in range(0, len(slices), 2):
+            if i + 1 < len(slices):
+                nxt.append(((slices[i].astype(np.float64) + slices[i + 1].astype(np.float64)) / 2.0).astype(np.float32))
+            else:
+                nxt.append(slices[i])
+            nt.append(times[i])
+        slices, times = nxt, nt
+    return slices, times
+
+
+def streaming_waterfall(chunks, sample_rate: float, *, nfft: int, hop: int | None = None, max_slices: int = 400):
+    """spectrum.py:58-93: (freqs, mean of the frames' dB values, times float32, matrix float32 [slices][nfft], frames)."""
+    hop = max(1, hop or nfft // 4)
+    max_slices = max(1, int(max_slices))
+    blocks = [np.asarray(c, dtype=np.complex64).reshape(-1) for c in chunks if c is not None]
+    blocks = [b for b in blocks if b.size]
+    stream = np.concatenate(blocks) if blocks else np.empty(0, dtype=np.complex64)
+    starts = sliding_window_starts([b.size for b in blocks], nfft, hop)
+    if not starts:
+        raise ValueError("Input did not contain enough samples for one FFT frame.")
+    total = np.zeros(nfft, dtype=np.float64)
+    slices, times = [], []
+    for reported, s0 in starts:
+        db = psd_frame_db(stream[s0 : s0 + nfft], nfft, sample_rate)
+        total += db
+        slices.append(db.astype(np.float32))
+        times.append(float(reported / sample_rate))
+        slices, times = waterfall_reduce(slices, times, max_slices)
+    return (psd_freqs(nfft, sample_rate), total / len(starts), np.asarray(times, dtype=np.float32),
+            np.stack(slices, axis=0).astype(np.float32), len(starts))
+
+
 def fft_workers_auto() -> int | None:
     """processing.py:697-732 (non-frozen branch): min(12, max(2, cores-1)); None if <=2 cores."""
     n = os.cpu_count() or 1

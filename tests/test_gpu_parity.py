@@ -750,3 +750,59 @@ def test_multi_channel_single_pass_and_cli(A, tmp_path):
         pcm, rate = iqio.read_wav_pcm16_mono(out.with_name(f"a_{int(round(f))}.wav"))
         assert rate == 48000 and pcm.size == -(-(-(-raw.shape[0] // 26)) * 24000 // 48077)
     assert cli.main(["--in", str(tmp_path / "missing.wav"), "--ft", "1e6", "--fc", "1e6"]) == 1
+
+
+def test_spectrum_psd_and_waterfall_vs_reference_fixtures_and_oracle(A, golden):
+    """iq_to_audio_amd.spectrum (window + rocFFT double-complex FFT + dB/fftshift epilogue,
+    pairwise waterfall reduction on the device) against the reference's own outputs (tests/golden/spectrum.npz) and,
+    at the reference's default nfft = 2^18, against the oracle.  PSD values are compared in dB where the bin is
+    above the float64 FFT's own noise (1e-13 of the frame's peak power) and in linear power below it."""
+    from iq_to_audio_amd import spectrum as S
+    from test_oracle_golden import _spectrum_stream, spectrum_waterfall_chunks
+
+    def close(db, want):
+        db, want = np.asarray(db, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        lin, wlin = 10.0 ** (db / 10.0), 10.0 ** (want / 10.0)
+        floor = 1e-13 * wlin.max()
+        strong = wlin > 1e3 * floor
+        assert np.max(np.abs(db[strong] - want[strong])) < 1e-6
+        assert np.max(np.abs(lin - wlin)) < 10 * floor + 1e-18
+
+    g = golden("spectrum.npz")
+    for k in range(4):
+        seed, n, nfft, fs = g[f"psd{k}_case"]
+        freqs, psd = S.compute_psd(_spectrum_stream(int(seed), int(n)), float(fs), int(nfft))
+        np.testing.assert_array_equal(freqs, g[f"psd{k}_freqs"])
+        assert psd.dtype == np.float64
+        close(psd, g[f"psd{k}_db"])
+    for k in range(3):
+        nfft, hop, max_slices = (int(v) for v in g[f"wf{k}_case"])
+        freqs, avg, wf, frames = S.streaming_waterfall(spectrum_waterfall_chunks(g), 2.0e6, nfft=nfft,
+                                                       hop=None if hop < 0 else hop, max_slices=max_slices)
+        assert frames == int(g[f"wf{k}_frames"])
+        np.testing.assert_array_equal(freqs, g[f"wf{k}_freqs"])
+        np.testing.assert_array_equal(wf.times, g[f"wf{k}_times"])
+        assert wf.matrix.dtype == np.float32 and wf.matrix.shape == g[f"wf{k}_matrix"].shape
+        # rows are float32 dB values; the noise-floor bins differ by the FFT's rounding, compare where it is resolved
+        want = g[f"wf{k}_matrix"].astype(np.float64)
+        resolved = want > want.max() - 120.0
+        assert np.max(np.abs(wf.matrix.astype(np.float64)[resolved] - want[resolved])) < 2e-4
+        assert np.max(np.abs(avg - g[f"wf{k}_avg"])[g[f"wf{k}_avg"] > g[f"wf{k}_avg"].max() - 120.0]) < 1e-5
+    # the reference's default frame size on the benchmark capture: 2^18-point double-complex FFT
+    raw = O.synth_capture_s16(2.5e6, 0.5, 25e3)
+    x = O.ingest_to_complex64(raw.reshape(-1), "s16")
+    freqs, psd = S.compute_psd(x, 2.5e6)
+    wf_freqs, want = O.compute_psd(x, 2.5e6)
+    np.testing.assert_array_equal(freqs, wf_freqs)
+    close(psd, want)
+    assert abs(freqs[int(np.argmax(psd))] - 25e3) < 2.5e6 / (1 << 18) * 1.5
+    _, avg, wf, frames = S.streaming_waterfall([x[:400_000], x[400_000:]], 2.5e6, nfft=1 << 16, max_slices=40)
+    _, avg_o, times_o, matrix_o, frames_o = O.streaming_waterfall([x[:400_000], x[400_000:]], 2.5e6, nfft=1 << 16, max_slices=40)
+    assert frames == frames_o and wf.matrix.shape == matrix_o.shape
+    np.testing.assert_array_equal(wf.times, times_o)
+    resolved = matrix_o > matrix_o.max() - 110.0
+    assert np.max(np.abs(wf.matrix[resolved] - matrix_o[resolved])) < 2e-4
+    with pytest.raises(ValueError):
+        S.compute_psd(np.empty(0, dtype=np.complex64), 1e6)
+    with pytest.raises(ValueError):
+        S.streaming_waterfall([np.zeros(10, dtype=np.complex64)], 1e6, nfft=64)
