@@ -326,68 +326,70 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
     pcm[i] = static_cast<short>(fmin(fmax(v, -32768.0), 32767.0));
 }
 
-// 48 kHz polyphase resampler, float64 accumulate.  Row-stationary: outputs j and j+up use the
-// same polyphase row (phase p = (j*down) mod up).  A wave owns one row (or 1/split of its
-// outputs), keeps the row's taps in registers spread over 16 lanes (lane `sub` holds taps
-// sub, sub+16, ...), and computes FOUR outputs per pass, one per quarter-wave, so the
-// cross-lane reduction is 4 butterfly steps per 4 outputs.  Input windows are read as
-// contiguous 16-float runs; the table is read once in total.
+// 48 kHz polyphase resampler, float64 accumulate.  Row-stationary: outputs J and J+up use the same polyphase
+// row (phase p = (J*down) mod up), so the table is read once per `split` part.  A wave owns SIXTEEN CONSECUTIVE
+// output residues (rows p, p+inc, p+2inc, ... with inc = down mod up), one per group of four lanes, which keeps
+// that row's taps in registers (lane `sub` holds taps sub, sub+4, ...).  Per step g the wave produces the 16
+// consecutive outputs J0+16w .. +15 (+ g*up): their input windows overlap, and the cross-lane reduction is two
+// quad steps per output.  The kernel is bound by float64 issue (convert + FMA per tap), so what counts is
+// instructions per output: 16 lanes per output (four butterfly steps for five taps a lane) cost twice as much.
 constexpr int RS_WAVES = 4;
+constexpr int RS_LANES = 4;  // lanes per output
 
-template <int NI>  // taps per lane = ceil(row_len / 16)
+template <int NI>  // taps per lane = ceil(row_len / 4)
 __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
                                                                int down, int T, long long j0, long long n_out, float *y,
                                                                int split)
 {
-    const int lane = threadIdx.x & 63, sub = lane & 15, quarter = lane >> 4;
+    const int lane = threadIdx.x & 63, sub = lane & (RS_LANES - 1), slot = lane >> 2;
     const long long wid = static_cast<long long>(blockIdx.x) * RS_WAVES + (threadIdx.x >> 6);
-    const long long w = wid / split;  // residue of (j0 + jj) mod up handled by this wave
+    const long long w = wid / split;  // group of 16 residues of (j0 + jj) mod up handled by this wave
     const int part = static_cast<int>(wid - w * split);
-    if (w >= up) return;
+    if (w * 16 >= up) return;
     const int row_len = 2 * T + 1;
-    const long long jj0 = (w - (j0 % up) + up) % up;  // first output of this row
-    if (jj0 >= n_out) return;
-    const long long g_total = (n_out - jj0 + up - 1) / up;
-    const long long g_per = ((g_total + split - 1) / split + 3) & ~3LL;
-    const long long g_lo = part * g_per, g_hi = min(g_total, g_lo + g_per);
+    const long long g_all = (n_out + up - 1) / up;  // steps any residue can need
+    const long long g_per = (g_all + split - 1) / split;
+    const long long g_lo = part * g_per, g_hi = min(g_all, g_lo + g_per);
     if (g_lo >= g_hi) return;
-    const long long c0 = (j0 + jj0) * down;
-    const long long q0 = c0 / up;  // the only 64-bit division: successive outputs of a row advance q by `down`
+    // this quad's residue: first output jj0, its input position q0 and its row
+    const long long res = w * 16 + slot;
+    const bool ok = res < up;
+    const long long jj0 = ok ? ((res - (j0 % up) + up) % up) : n_out;  // >= n_out: never live
+    const long long c0 = (j0 + (ok ? jj0 : 0)) * down;
+    const long long q0 = c0 / up;
     const int p = static_cast<int>(c0 - q0 * up);
     const double *row = table + static_cast<long long>(p) * row_len;
-    // All loads below are unconditional (clamped index, masked afterwards): a branch around a load makes hipcc
-    // wait for every load separately, which is what made the first versions of this kernel latency-bound.
+    // all loads unconditional (clamped index, masked afterwards): a branch around a load makes hipcc wait for
+    // every load separately
     double h[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) h[i] = row[min(sub + 16 * i, row_len - 1)];
+    for (int i = 0; i < NI; ++i) h[i] = row[min(sub + RS_LANES * i, row_len - 1)];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-        if (sub + 16 * i >= row_len) h[i] = 0.0;
-    for (long long g = g_lo + quarter; g < g_hi + quarter; g += 4) {  // all quarters iterate together
-        const bool live = g < g_hi;
+        if (sub + RS_LANES * i >= row_len) h[i] = 0.0;
+    for (long long g = g_lo; g < g_hi; ++g) {
         const long long jj = jj0 + g * up;
-        const long long q = q0 + g * down;
-        const long long top = q + T - sub;  // input index of this lane's first tap; tap i reads top - 16 i
+        const long long top = q0 + g * down + T - sub;  // input index of this lane's first tap; tap i reads top - 4 i
         double acc = 0.0;
-        if (top - 16 * (NI - 1) >= 0 && top < n_in) {
+        if (top - RS_LANES * (NI - 1) >= 0 && top < n_in) {
             // interior (almost always): one 64-bit base, immediate offsets, no clamps
             const float *xp = x + top;
             float xv[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) xv[i] = xp[-16 * i];
+            for (int i = 0; i < NI; ++i) xv[i] = xp[-RS_LANES * i];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) acc = fma(h[i], static_cast<double>(live ? xv[i] : 0.f), acc);
+            for (int i = 0; i < NI; ++i) acc = fma(h[i], static_cast<double>(xv[i]), acc);
         } else {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const long long nidx = top - 16 * i;
-                const float v = x[min(max(nidx, 0LL), n_in - 1)];
-                acc = fma(h[i], static_cast<double>((live && nidx >= 0 && nidx < n_in) ? v : 0.f), acc);
+                const long long nidx = top - RS_LANES * i;
+                const float v = x[min(max(nidx, 0LL), max(n_in - 1, 0LL))];
+                acc = fma(h[i], static_cast<double>((nidx >= 0 && nidx < n_in) ? v : 0.f), acc);
             }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);  // stays inside the 16-lane group
-        if (live && sub == 0) y[jj] = static_cast<float>(acc);
+        acc += __shfl_xor(acc, 2, kWave);
+        acc += __shfl_xor(acc, 1, kWave);  // stays inside the quad
+        if (jj < n_out && sub == 0) y[jj] = static_cast<float>(acc);
     }
 }
 
@@ -553,17 +555,19 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     if (!table_dev || !y_dev || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
     if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
     const int64_t g_total = (n_out + up - 1) / up;  // outputs per polyphase row
-    const int split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(16, (g_total + 31) / 32)));
-    const dim3 grid = grid1d(static_cast<int64_t>(up) * split, RS_WAVES), block(RS_WAVES * kWave);
-    const int ni = (2 * T + 1 + 15) / 16;
+    // enough waves to fill the chip (>= ~8 per SIMD) while a wave still amortises its 4*NI tap loads over several steps
+    const int64_t groups = (static_cast<int64_t>(up) + 15) / 16;
+    const int split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_total, (8192 + groups - 1) / groups)));
+    const dim3 grid = grid1d(groups * split, RS_WAVES), block(RS_WAVES * kWave);
+    const int ni = (2 * T + 1 + 3) / 4;
 #define IQA_RS_LAUNCH(NI)                                                                                          \
     hipLaunchKernelGGL((k_resample<NI>), grid, block, 0, as_stream(stream), static_cast<const float *>(x_dev),     \
                        (long long)n_in, static_cast<const double *>(table_dev), (int)up, (int)down, (int)T,        \
                        (long long)j0, (long long)n_out, static_cast<float *>(y_dev), split)
-    if (ni <= 5) IQA_RS_LAUNCH(5);
-    else if (ni <= 6) IQA_RS_LAUNCH(6);
-    else if (ni <= 8) IQA_RS_LAUNCH(8);
-    else IQA_RS_LAUNCH(12);
+    if (ni <= 17) IQA_RS_LAUNCH(17);
+    else if (ni <= 24) IQA_RS_LAUNCH(24);
+    else if (ni <= 32) IQA_RS_LAUNCH(32);
+    else IQA_RS_LAUNCH(48);
 #undef IQA_RS_LAUNCH
     return check_launch("k_resample");
 }
