@@ -38,6 +38,7 @@ struct FusedArgs {
     double *carry;
     double *fin;
     int nblocks;
+    int z_aligned, y_aligned;  // z / y are 16-byte aligned: the vector load / store paths may be used
 };
 
 template <int SRC>
@@ -68,10 +69,41 @@ __device__ __forceinline__ void load_u(const FusedArgs &a, long long base, float
         }
     } else {
         float2 zz[SC_ITEMS + 2];  // z[base-2 .. base+7]
+        static_assert(SC_ITEMS == 8, "the vector path below moves 8 float2 = 4 x 16 bytes per thread");
+        // Whole-wave fast path (every tile but the last): a thread's eight samples are 64 contiguous, 16-byte
+        // aligned bytes -> four 16-byte loads; the two samples in front of them are the previous lane's last two
+        // (one shuffle each) except for lane 0.  Scalar float2 loads at a 64-byte lane stride cost 2.5x the
+        // load instructions and touch every line five times.
+        const int lane = threadIdx.x & 63;
+        const long long wave_base = base - static_cast<long long>(lane) * SC_ITEMS;
+        if (a.z_aligned && wave_base + 64 * SC_ITEMS <= a.n) {
+            const float4 *p = reinterpret_cast<const float4 *>(a.z + base);
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            zz[2] = make_float2(q0.x, q0.y);
+            zz[3] = make_float2(q0.z, q0.w);
+            zz[4] = make_float2(q1.x, q1.y);
+            zz[5] = make_float2(q1.z, q1.w);
+            zz[6] = make_float2(q2.x, q2.y);
+            zz[7] = make_float2(q2.z, q2.w);
+            zz[8] = make_float2(q3.x, q3.y);
+            zz[9] = make_float2(q3.z, q3.w);
+            float2 e0 = make_float2(0.f, 0.f), e1 = make_float2(0.f, 0.f);
+            if (lane == 0 && base >= 2) {
+                e0 = a.z[base - 2];
+                e1 = a.z[base - 1];
+            }
+            zz[0] = make_float2(__shfl_up(q3.x, 1, kWave), __shfl_up(q3.y, 1, kWave));
+            zz[1] = make_float2(__shfl_up(q3.z, 1, kWave), __shfl_up(q3.w, 1, kWave));
+            if (lane == 0) {
+                zz[0] = e0;
+                zz[1] = e1;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < SC_ITEMS + 2; ++i) {
-            const long long k = base - 2 + i;
-            zz[i] = (k >= 0 && k < a.n) ? a.z[k] : make_float2(0.f, 0.f);
+            for (int i = 0; i < SC_ITEMS + 2; ++i) {
+                const long long k = base - 2 + i;
+                zz[i] = (k >= 0 && k < a.n) ? a.z[k] : make_float2(0.f, 0.f);
+            }
         }
         if constexpr (SRC == S_QUAD) {
             if (base == 0) zz[1] = a.prev[0];  // z[-1]
@@ -223,15 +255,17 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
     if (stats && !uniform && base < a.n) seg = lower_bound_ll(a.segs, a.n_segs, base + 1) - 1;
     float pk = 0.f;
     double run = 0.0;
+    float vout[SC_ITEMS];
 #pragma unroll
     for (int i = 0; i < SC_ITEMS; ++i) {
         s = fma(m[i].A, s, m[i].B);
         const long long idx = base + i;
+        vout[i] = 0.f;
         if (idx < a.n) {
             const float v = (OP == F_AGC) ? u[i] * static_cast<float>(s) : static_cast<float>(s);
             if constexpr (SINK == K_CLIP) {
                 pk = fmaxf(pk, fabsf(v));
-                a.y[idx] = fminf(fmaxf(v, -0.99f), 0.99f);
+                vout[i] = fminf(fmaxf(v, -0.99f), 0.99f);
                 if (stats) {
                     if (!uniform) {
                         while (seg + 1 < a.n_segs && a.segs[seg + 1] <= idx) {
@@ -243,9 +277,18 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
                     run += static_cast<double>(v) * static_cast<double>(v);
                 }
             } else {
-                a.y[idx] = v;
+                vout[i] = v;
             }
         }
+    }
+    if (a.y_aligned && base + SC_ITEMS <= a.n) {  // 32 contiguous, aligned bytes per thread: two 16-byte stores
+        float4 *yp = reinterpret_cast<float4 *>(a.y + base);
+        yp[0] = make_float4(vout[0], vout[1], vout[2], vout[3]);
+        yp[1] = make_float4(vout[4], vout[5], vout[6], vout[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i)
+            if (base + i < a.n) a.y[base + i] = vout[i];
     }
     if constexpr (SINK == K_CLIP) {
         if (stats && !uniform && run != 0.0) atomicAdd(&a.sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
@@ -325,6 +368,8 @@ extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int6
     a.peak_bits = static_cast<unsigned int *>(peak_dev);
     a.sumsq = static_cast<double *>(sumsq_dev);
     a.y = static_cast<float *>(audio_out_dev);
+    a.z_aligned = (reinterpret_cast<uintptr_t>(z_dev) & 15) == 0;
+    a.y_aligned = (reinterpret_cast<uintptr_t>(audio_out_dev) & 15) == 0;
     a.prev = reinterpret_cast<const float2 *>(st);
     if (p->mode == IQA_DEMOD_NFM) {
         a.p0 = p->deemph_alpha;
@@ -343,6 +388,7 @@ extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int6
     if (!scratch_dev) return fail_inval("SSB with AGC needs a float scratch buffer of n elements");
     FusedArgs d = a;
     d.y = static_cast<float *>(scratch_dev);
+    d.y_aligned = (reinterpret_cast<uintptr_t>(scratch_dev) & 15) == 0;
     d.peak_bits = nullptr;
     d.sumsq = nullptr;
     int rc = launch_fused<F_DC, S_REAL, K_PLAIN>(d, nullptr, dc_out, work_dev, s);

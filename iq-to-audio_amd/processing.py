@@ -696,7 +696,7 @@ class ResidentCaptureRunner:
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
-                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, tail_stream: bool = False):
+                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, tail_stream: bool = False, probe_stream: bool = False):
         torch = D.torch_mod()
         self.taps, self.fs, self.f_off, self.d, self.fs_ch = np.asarray(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
         self.chunk, self.n_frames, self.fmt, self.iq_order = int(chunk), int(n_frames), fmt, iq_order
@@ -712,6 +712,11 @@ class ResidentCaptureRunner:
         # so the default keeps one compute stream; only the D2H runs beside it.
         self.tail = torch.cuda.Stream() if tail_stream else self.compute
         self.egress = torch.cuda.Stream()
+        # probe_stream=True runs the probes (off the critical path: the channelizer is speculative) on their own stream,
+        # gated to start when the previous capture's channelizer has finished.  Measured: no gain -- whatever part of
+        # them is caught beside the next channelizer is starved and stretches it by 10 % -- so it is off by default.
+        self.probe_stream = torch.cuda.Stream() if probe_stream else None
+        self._ring_done = None
         self.slots = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
                            pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(), busy=None,
                            dem=ChannelDemod(demod_mode, self.fs_ch, deemph_us=deemph_us, agc_enabled=agc_enabled))
@@ -734,6 +739,8 @@ class ResidentCaptureRunner:
         gate.record()  # compute stream: behind this capture's probes, in front of its channelizer
         prev = self._egress_pending
         chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True)
+        self._ring_done = torch.cuda.Event()
+        self._ring_done.record()
         if prev is not None:
             self._flush_egress(gate)  # the previous capture's D2H runs beside the channelizer, not beside the probes
         if self.tail is not self.compute:
@@ -788,8 +795,11 @@ class ResidentCaptureRunner:
             warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
             ready = torch.cuda.Event()
             ready.record()
-            self.tail.wait_event(ready)  # raw_dev was produced on the caller's stream
-            with torch.cuda.stream(self.tail):
+            ps = self.probe_stream if self.probe_stream is not None else self.tail
+            ps.wait_event(ready)  # raw_dev was produced on the caller's stream
+            if self.probe_stream is not None and self._ring_done is not None:
+                ps.wait_event(self._ring_done)
+            with torch.cuda.stream(ps):
                 probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order)
         sign = self.override if self.override is not None else 1
         ticket = self._chain(raw_dev, slot, sign, events)
