@@ -41,6 +41,10 @@ constexpr int RG_GUARD = 64;   // a tile's scatter reaches at most 59 positions 
 constexpr int RG_AS = RG_W + RG_GUARD;
 constexpr int RG_ACC_BYTES = 2 * RG_AS * 4;
 constexpr int RG_EMIT_WAVE = 2;  // (rt 2, parity 0): not an issuing wave
+// Parity-1 waves scatter a tile one round late (at the start of the next round, while their SIMD partner of parity 0
+// is already multiplying -- the two waves of a SIMD then alternate between the matrix pipe and the LDS instead of
+// meeting in both), so a group of 64 outputs is final three rounds after its first tile.
+constexpr int RG_EMIT_LAG = 3;
 
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
@@ -167,19 +171,20 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
         if (STREAM) ring_wait_and_barrier<KS>(min(R - 2, c.rounds - 1 - r), 0);
         else asm volatile("s_barrier" ::: "memory");
         if (STREAM && r + R - 1 < c.rounds) issue_tile(2 * (r + R - 1) + cp, (slot == 0) ? R - 1 : slot - 1);
-        if (r >= 2 && ((r - 2) & 1) == cp) {
-            // every wave has ISSUED its LDS adds of round r-1 before this barrier; a wave has at most 15 LDS
-            // operations outstanding and they complete in order, so all adds of round r-2 and earlier -- everything
-            // that reaches positions <= 64 (r-1) -- have landed.
+        if (r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) {
+            // every wave has ISSUED the LDS adds of its round r-2 tile before this barrier (parity 1 defers a tile's
+            // adds to the start of the next round); a wave has at most 15 LDS operations outstanding and they complete
+            // in order, so the adds of the tiles of round r-3 and earlier -- everything that reaches positions
+            // <= 64 (r-2) -- have landed.
             asm volatile("" ::: "memory");
-            ring_emit_group(a2, c, em, r - 2);
+            ring_emit_group(a2, c, em, r - RG_EMIT_LAG);
             asm volatile("" ::: "memory");
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int k_last = (c.cnt + 62) >> 6;
-    for (int k = max(c.rounds - 2, 0); k <= k_last; ++k)
+    for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k)
         if ((k & 1) == cp) ring_emit_group(a2, c, em, k);
 }
 
@@ -187,7 +192,7 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ISSUER, bool EMIT>
+template <int KS, int DBG, bool ISSUER, bool EMIT, bool DEFER>
 __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
 {
     constexpr int R = ring_rounds(KS);
@@ -212,14 +217,36 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &em.ws, &em.wc);
     }
     const v16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // diagonal scatter of a finished tile into the window of sums (row = q, column = data row: output = row + column).
+    // Written as inline asm on purpose: the compiler drains vmcnt to 0 before any LDS store it can see while LDS-DMAs
+    // are in flight (it cannot tell the ring from the window), which would serialise the whole prefetch pipeline once
+    // per round.  These adds touch the window only, never the ring.
+    auto scatter = [&](int t, const v16i_t &acc1, const v16i_t &acc2) {
+        const unsigned p = lds_addr(c.s_acc + ((t * 32 + c.col + 4 * c.h + 1) & (RG_W - 1)) + (rt >> 1) * RG_AS + (rt & 1) * 32);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            // 256*S1 + S2 in ONE int32 (the host bounds the tap magnitudes so that this cannot overflow for any input,
+            // dsp_plan.plan_mfma(acc32=True)); the shift-add is a VALU op the compiler can see, so the MFMA -> VALU
+            // hazard distance is its business and the asm reads a VALU result
+            const int comb = (acc1[q] << 8) + acc2[q];
+            const int off = 4 * ((q & 3) + 8 * (q >> 2));
+            asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(p), "v"(comb), "n"(off));
+        }
+    };
+    v16i_t held1 = zero16, held2 = zero16;  // DEFER: the previous tile's sums, scattered at the start of the next round
+    int held_t = -1;
     int slot = 0;
     for (int r = 0; r < c.rounds; ++r) {
         if (STREAM) ring_wait_and_barrier<KS>(min(R - 2, c.rounds - 1 - r), 0);
         else asm volatile("s_barrier" ::: "memory");
-        if (EMIT && r >= 2) {
+        if (EMIT && r >= RG_EMIT_LAG) {
             asm volatile("" ::: "memory");
-            ring_emit_group(a, c, em, r - 2);  // see ring_loader for why these sums are final
+            ring_emit_group(a, c, em, r - RG_EMIT_LAG);  // see ring_loader for why these sums are final
             asm volatile("" ::: "memory");
+        }
+        if (DEFER && held_t >= 0) {
+            scatter(held_t, held1, held2);
+            held_t = -1;
         }
         const bool pf = STREAM && (r + R - 1 < c.rounds);
         const int pf_tile = 2 * (r + R - 1) + cp;
@@ -269,22 +296,12 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 if (DBG & 32) acc1 = acc2 = zero16;
                 if (DBG & 1) {
                     asm volatile("" ::"v"(acc1), "v"(acc2));
+                } else if (DEFER) {
+                    held1 = acc1;
+                    held2 = acc2;
+                    held_t = t;
                 } else {
-                    // diagonal scatter into the window of sums (row = q, column = data row: output = row + column).
-                    // Written as inline asm on purpose: the compiler drains vmcnt to 0 before any LDS store it can see
-                    // while LDS-DMAs are in flight (it cannot tell the ring from the window), which would serialise
-                    // the whole prefetch pipeline once per round.  These adds touch the window only, never the ring.
-                    const unsigned p = lds_addr(c.s_acc + ((t * 32 + c.col + 4 * c.h + 1) & (RG_W - 1)) + (rt >> 1) * RG_AS +
-                                                (rt & 1) * 32);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        // 256*S1 + S2 in ONE int32 (the host bounds the tap magnitudes so that this cannot overflow for
-                        // any input, dsp_plan.plan_mfma(acc32=True)); the shift-add is a VALU op the compiler can see, so
-                        // the MFMA -> VALU hazard distance is its business and the asm reads a VALU result
-                        const int comb = (acc1[q] << 8) + acc2[q];
-                        const int off = 4 * ((q & 3) + 8 * (q >> 2));
-                        asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(p), "v"(comb), "n"(off));
-                    }
+                    scatter(t, acc1, acc2);
                 }
             };
             if (pf) tile_body(std::true_type{});
@@ -295,11 +312,12 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
+    if (DEFER && held_t >= 0) scatter(held_t, held1, held2);
     // the last groups: everything has landed behind a full wait and one more barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (EMIT) {
         const int k_last = (c.cnt + 62) >> 6;
-        for (int k = max(c.rounds - 2, 0); k <= k_last; ++k) ring_emit_group(a, c, em, k);
+        for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k) ring_emit_group(a, c, em, k);
     }
 }
 
@@ -362,11 +380,17 @@ __global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) v
     }
     __syncthreads();
     c.stream0 = stream + (c.rt & 1) * 1024;
-    if (LOADERS) ring_main<KS, DBG, false, false>(a, c, fq);
+    if (LOADERS) {
+        if (c.cp) ring_main<KS, DBG, false, false, true>(a, c, fq);
+        else ring_main<KS, DBG, false, false, false>(a, c, fq);
+    }
     // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
-    else if ((c.rt >> 1) == c.cp) ring_main<KS, DBG, true, false>(a, c, fq);
-    else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, false, true>(a, c, fq);
-    else ring_main<KS, DBG, false, false>(a, c, fq);
+    else if ((c.rt >> 1) == c.cp) {
+        if (c.cp) ring_main<KS, DBG, true, false, true>(a, c, fq);
+        else ring_main<KS, DBG, true, false, false>(a, c, fq);
+    } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, false, true, false>(a, c, fq);
+    else if (c.cp) ring_main<KS, DBG, false, false, true>(a, c, fq);
+    else ring_main<KS, DBG, false, false, false>(a, c, fq);
 }
 
 bool mfma_ring_supported(int decimation)
