@@ -87,7 +87,12 @@ def main() -> None:
     host = synthetic_iq_s16(fs, n_unique / fs, f_off, seed=42 + rank).reshape(-1)
     tile = torch.from_numpy(host).to(D.device())
     reps = -(-n_total // n_unique)
-    raw = tile.repeat(reps)[: 2 * n_total].contiguous()
+    # the capture sits inside a slightly larger buffer: a few KB of readable slack behind it make the last outputs
+    # interior outputs of the matrix-core kernel too (no VALU tail launch)
+    lead, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    buf = torch.zeros(2 * (lead + n_total + slack), dtype=torch.int16, device=D.device())
+    buf[2 * lead : 2 * (lead + n_total)] = tile.repeat(reps)[: 2 * n_total]
+    raw = buf[2 * lead : 2 * (lead + n_total)]
     del tile
     torch.cuda.synchronize()
 
@@ -104,7 +109,7 @@ def main() -> None:
     tickets = []
 
     def step(i: int):
-        t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]))
+        t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]), enclosing=buf, lead_frames=lead)
         tickets.append(t)
         if world > 1:
             runner.egress.wait_event(t["tail_done"])  # this capture's PCM16 is complete

@@ -112,6 +112,9 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
  * It covers only outputs whose whole read range lies inside raw_dev[0, n_frames): columns
  * (m_first-64)*D+1 ... ; the caller runs iqa_channelize for the few outputs at the block's head
  * (history) and tail.
+ * Here (unlike iqa_channelize) `consumed` may be negative: raw_dev then starts |consumed| frames before global
+ * frame 0 and those frames must be zero (the filter's zero initial state, OverlapSaveFIR.state processing.py:323);
+ * with such a lead-in and some readable slack behind the capture every output of a capture is an interior one.
  *   afrag_dev : tap fragments of THIS pass, k_count*8192 bytes, layout [kstep][rowtile 4][piece 2][lane 64][16 B]
  *               (host: dsp_plan.plan_mfma); unit/c_re/c_im from the same quantisation.
  * One call is one PASS over (q-group, k-step range).  A filter with ceil(L/D) <= 64 whose fragments fit

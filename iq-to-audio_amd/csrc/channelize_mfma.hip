@@ -444,7 +444,9 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     if (p->fmt != IQA_FMT_S16) return fail_inval("the MFMA channelizer takes int16 captures only");
     if (p->ntaps <= 0 || p->decimation < 1) return fail_inval("bad ntaps/decimation");
     const int64_t D = p->decimation;
-    if (n_out < 0 || n_frames < 0 || consumed < 0 || m_first < 0) return fail_inval("negative size");
+    // consumed may be negative: raw_dev then starts |consumed| frames BEFORE global frame 0 (a lead-in of zeros --
+    // the filter's initial state -- in front of the capture, so that the first outputs are interior outputs too)
+    if (n_out < 0 || n_frames < 0 || m_first < 0) return fail_inval("negative size");
     if (n_out == 0) return IQA_OK;
     if (!afrag_dev || !raw_dev || !z_out_dev) return fail_inval("NULL device pointer");
     const int ksteps_all = static_cast<int>((2 * D + 31) / 32);

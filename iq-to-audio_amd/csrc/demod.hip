@@ -244,6 +244,29 @@ __global__ __launch_bounds__(256) void k_mean_power(const float2 *z, long long n
     if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * inv_count);
 }
 
+// Short inputs (the mixer-sign probes: a few thousand samples): one block, fixed summation order, the result is
+// WRITTEN -- no memset in front, no atomics.
+__global__ __launch_bounds__(1024) void k_mean_power_small(const float2 *z, long long n, long long skip, double inv_count,
+                                                            double *out)
+{
+    __shared__ double s_w[16];
+    double acc = 0.0;
+    for (long long i = skip + threadIdx.x; i < n; i += 1024) {
+        const float2 v = z[i];
+        const float m = hypotf(v.x, v.y);
+        acc += static_cast<double>(m * m);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        out[0] = t * inv_count;
+    }
+}
+
 // AudioWriter.write: running pre-clip peak, clip, per-segment sum of squares (float64).
 // One float64 atomic per block when the block lies inside one segment (the common case: a
 // reference chunk is >= 40k channel-rate samples); per-thread flushes only for blocks that
@@ -520,11 +543,17 @@ extern "C" int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *
     if (n < 0 || skip < 0 || skip > n) return fail_inval("bad range");
     if (!power_dev) return fail_inval("NULL device pointer");
     hipStream_t s = as_stream(stream);
+    const int64_t count = n - skip;
+    if (count > 0 && count <= 65536) {
+        if (!z_dev) return fail_inval("NULL device pointer");
+        hipLaunchKernelGGL(k_mean_power_small, dim3(1), dim3(1024), 0, s, static_cast<const float2 *>(z_dev), (long long)n,
+                           (long long)skip, 1.0 / static_cast<double>(count), static_cast<double *>(power_dev));
+        return check_launch("k_mean_power_small");
+    }
     if (hipMemsetAsync(power_dev, 0, sizeof(double), s) != hipSuccess) {
         set_error("hipMemsetAsync failed");
         return IQA_EHIP;
     }
-    const int64_t count = n - skip;
     if (count == 0) return IQA_OK;
     if (!z_dev) return fail_inval("NULL device pointer");
     const int64_t blocks = std::min<int64_t>((count + 255) / 256, 2048);

@@ -304,7 +304,7 @@ def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decima
     """(m_a, m_b): the sub-range of outputs [m_first, m_first+n_out) whose whole MFMA read range
     (columns m-64*n_groups .. m+29, each 16*ksteps frames from frame b*D+1) lies inside this block's frames."""
     d = decimation
-    m_a = max(m_first, MFMA_Q * n_groups + -(-max(consumed - 1, 0) // d))
+    m_a = max(m_first, MFMA_Q * n_groups + -(-(consumed - 1) // d))  # consumed < 0: a lead-in in front of frame 0
     m_b = min(m_first + n_out, (n_frames + consumed - 16 * ksteps) // d - 30)
     return (m_a, m_b) if m_b > m_a else (m_first, m_first)
 

@@ -222,41 +222,72 @@ class _ChannelKernel:
                    c_int64(consumed), N.ptr(hist_dev), c_int64(m_first), c_int64(n_out), N.ptr(out_dev), N.stream_ptr())
 
     def run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev=None,
-            events=None):
-        """``events``: optional (start, stop) torch.cuda.Event pair recorded around the dominant launch."""
+            events=None, halo=None):
+        """``events``: optional (start, stop) torch.cuda.Event pair recorded around the dominant launch.
+        ``halo``: optional (buffer, lead_frames) -- ``raw_dev`` is the slice ``buffer[lead : lead + n_frames]`` (in
+        frames) of a larger device buffer whose ``lead`` frames in front hold the history of this block (zeros at the
+        start of a capture) and whose frames behind may be read (their values are never used): the matrix-core
+        kernels then cover the block's first and last outputs too and the two VALU edge launches disappear."""
         with self._lock:
-            return self._run(raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev, events)
+            return self._run(raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev, events, halo)
 
-    def _run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev, events):
+    def _interior(self, consumed: int, n_frames: int, m_first: int, n_out: int) -> tuple[int, int]:
+        """Outputs [m_a, m_b) the matrix-core kernels can produce from this block's frames alone."""
+        d = self.plan.decimation
+        ksteps = -(-2 * d // 32)
+        n_groups = max(1, -(-(-(-self.plan.ntaps // d)) // P.MFMA_Q))
+        m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, d, ksteps, n_groups)
+        if self.mfma_variant == "ring" and self._ring_bytes:
+            # a ring tile is fetched as 2048*ksteps contiguous bytes from its first frame
+            m_b = min(m_b, (n_frames + consumed - 512 * ksteps - 1) // d + 2)
+        return (m_a, m_b) if m_b > m_a else (m_first, m_first)
+
+    def _mfma_passes(self, raw_dev, n_frames: int, consumed: int, m_a: int, n_int: int, out_dev, min_block: int = 512):
+        mp = self._ensure_mfma()
+        self.last_kernel = "k_channelize_mfma_s16" + ("_ring" if self._pass_variant[-1] == "ring" else "")
+        partial = D.empty(2 * n_int, "float64") if len(mp.passes) > 1 else None
+        for i, (ps, prm) in enumerate(zip(mp.passes, self.mfma_params)):
+            last = i == len(mp.passes) - 1
+            rng = self._block_outputs(n_int, self._range_max(ps.k_count, self._pass_variant[i]))
+            if self._pass_variant[i] == "ring" and min_block < 512:  # short launches: more, smaller blocks
+                rng = max(min_block, min(rng, -(-(-(-n_int // 256)) // 32) * 32))
+            prm.outputs_per_block = rng
+            prm.finalize = int(last)
+            prm.partial_in_dev = partial.data_ptr() if (partial is not None and i > 0) else None
+            prm.partial_out_dev = partial.data_ptr() if (partial is not None and not last) else None
+            afrag = self.afrag_dev[ps.group][ps.k_first * P.MFMA_KSTEP_BYTES :]
+            N.call("iqa_channelize_mfma", byref(self.params), byref(prm), N.ptr(afrag), N.ptr(raw_dev),
+                   c_int64(n_frames), c_int64(consumed), c_int64(m_a), c_int64(n_int), N.ptr(out_dev), N.stream_ptr())
+
+    def run_interior_only(self, raw_dev, n_frames: int, m_first: int, n_out: int, out_dev) -> bool:
+        """Outputs [m_first, m_first + n_out) of a block that starts the capture (consumed = 0), matrix-core kernels
+        only -- for callers that do not want the outputs near the block's edges (the mixer-sign probes discard the
+        filter's transient and read a snippet of a longer buffer).  False (nothing launched) when the range is not
+        wholly interior or the capture format has no matrix-core kernel."""
+        with self._lock:
+            if not (self._mfma_ok and self.mfma_variant == "ring" and self._ring_bytes) or n_out < 64:
+                return False
+            m_a, m_b = self._interior(0, n_frames, m_first, n_out)
+            if m_a != m_first or m_b != m_first + n_out:
+                return False
+            self._mfma_passes(raw_dev, n_frames, 0, m_first, n_out, out_dev, min_block=64)
+            return True
+
+    def _run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev, events, halo=None):
         if out_dev is None:
             out_dev = D.empty(n_out, "complex64")
         self.last_kernel = "k_channelize_v1"
         if self._mfma_ok and n_out >= self.mfma_min_outputs:
-            d = self.plan.decimation
-            ksteps = -(-2 * d // 32)
-            n_groups = max(1, -(-(-(-self.plan.ntaps // d)) // P.MFMA_Q))
-            m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, d, ksteps, n_groups)
-            if self.mfma_variant == "ring" and self._ring_bytes:
-                # a ring tile is fetched as 2048*ksteps contiguous bytes from its first frame
-                m_b = min(m_b, (n_frames + consumed - 512 * ksteps - 1) // d + 2)
+            big, big_frames, big_consumed = raw_dev, n_frames, consumed
+            if halo is not None:  # the matrix-core kernels address the enclosing buffer
+                big, lead = halo
+                big_frames, big_consumed = int(big.numel()) // 2, consumed - int(lead)
+            m_a, m_b = self._interior(big_consumed, big_frames, m_first, n_out)
             if m_b - m_a >= self.mfma_min_outputs:
-                mp = self._ensure_mfma()
-                n_int = m_b - m_a
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
-                self.last_kernel = "k_channelize_mfma_s16" + ("_ring" if self._pass_variant[-1] == "ring" else "")
-                partial = D.empty(2 * n_int, "float64") if len(mp.passes) > 1 else None
                 if events:
                     events[0].record()
-                for i, (ps, prm) in enumerate(zip(mp.passes, self.mfma_params)):
-                    last = i == len(mp.passes) - 1
-                    prm.outputs_per_block = self._block_outputs(n_int, self._range_max(ps.k_count, self._pass_variant[i]))
-                    prm.finalize = int(last)
-                    prm.partial_in_dev = partial.data_ptr() if (partial is not None and i > 0) else None
-                    prm.partial_out_dev = partial.data_ptr() if (partial is not None and not last) else None
-                    afrag = self.afrag_dev[ps.group][ps.k_first * P.MFMA_KSTEP_BYTES :]
-                    N.call("iqa_channelize_mfma", byref(self.params), byref(prm), N.ptr(afrag), N.ptr(raw_dev),
-                           c_int64(n_frames), c_int64(consumed), c_int64(m_a), c_int64(n_int),
-                           N.ptr(out_dev[m_a - m_first :]), N.stream_ptr())
+                self._mfma_passes(big, big_frames, big_consumed, m_a, m_b - m_a, out_dev[m_a - m_first :])
                 if events:
                     events[1].record()
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_b, m_first + n_out - m_b, out_dev[m_b - m_first :])
@@ -400,15 +431,19 @@ class Channelizer:
         m_end = -(-(self.consumed + n_frames) // d)
         return m_first, m_end - m_first
 
-    def process(self, raw, out_dev=None, events=None, last_block: bool = False):
+    def process(self, raw, out_dev=None, events=None, last_block: bool = False, halo=None):
         """``raw``: interleaved frames (NumPy or device tensor, dtype of ``fmt``; complex64 for f32).
         Returns the decimated complex64 samples for this block.  ``last_block``: nothing follows, so the
-        L-1 frame history is not carried over (saves a launch for whole-capture calls)."""
+        L-1 frame history is not carried over (saves a launch for whole-capture calls).  ``halo``: see
+        ``_ChannelKernel.run`` (int16 device captures only)."""
         x, n = _as_frames(raw, self.fmt)
         if n == 0:
             return D.like_input(D.empty(0, "complex64"), raw)
         m_first, n_out = self.outputs_for(n)
-        z = self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events) if n_out else D.empty(0, "complex64")
+        if halo is not None and (self.fmt != "s16" or not D.is_tensor(raw)):
+            halo = None
+        z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo)
+             if n_out else D.empty(0, "complex64"))
         keep = 0 if last_block else self.ntaps - 1
         if keep:
             nxt = D.empty(keep * iqio.FRAME_BYTES[self.fmt], "uint8")
@@ -465,12 +500,24 @@ class MixSignProbe:
             snippet_len = min(n_in, ntaps * 2)
         x = x_all[:snippet_len] if x_all.is_complex() else x_all[: 2 * snippet_len]
         decim = max(decimation, 1)
-        self._powers = D.zeros(2, "float64")
+        self._powers = D.empty(2, "float64")  # iqa_mean_power overwrites its slot
         self._host = _pinned_scalars(id(self))
         self._sign = None
         for i, sign in enumerate((1, -1)):
             ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
                              fmt=fmt, iq_order=iq_order)
+            n_z = -(-snippet_len // decim)
+            discard = min(ntaps, n_z // 4)
+            if n_z - discard == 0:
+                discard = 0
+            # Only z[discard:] enters the power (processing.py:651-656), and those outputs see neither the zero
+            # initial state nor anything past the snippet: when the warm-up buffer is longer than the snippet they are
+            # all interior outputs of the matrix-core kernel -- one launch per sign instead of three.
+            z_keep = D.empty(n_z - discard, "complex64")
+            if fmt == "s16" and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
+                _mean_power_into(z_keep, 0, self._powers[i : i + 1])
+                self._valid[i] = True
+                continue
             z = ch.process(x, last_block=True)
             if z.numel():
                 discard = min(ntaps, z.numel() // 4)
@@ -725,7 +772,7 @@ class ResidentCaptureRunner:
         self._egress_pending = None  # ticket whose D2H has not been queued yet (see _flush_egress)
         self.egress_workgroups = 8
 
-    def _chain(self, raw_dev, slot, sign: int, events=None):
+    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None):
         """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
         torch = D.torch_mod()
         chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
@@ -738,7 +785,7 @@ class ResidentCaptureRunner:
         gate = torch.cuda.Event()
         gate.record()  # compute stream: behind this capture's probes, in front of its channelizer
         prev = self._egress_pending
-        chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True)
+        chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo)
         self._ring_done = torch.cuda.Event()
         self._ring_done.record()
         if prev is not None:
@@ -781,8 +828,21 @@ class ResidentCaptureRunner:
         t["egress_queued"] = True
         self._egress_pending = None
 
-    def submit(self, raw_dev, events=None) -> dict:
-        """Queue one capture (device tensor of interleaved frames, ``n_frames`` long).  Returns a ticket for ``collect``."""
+    @staticmethod
+    def padded_capture_frames(decimation: int, ntaps: int) -> tuple[int, int]:
+        """(lead, slack) frames a capture buffer should carry in front of / behind the capture: ``slack`` readable
+        (ignored) frames behind it make the LAST outputs interior outputs of the matrix-core channelizer (no VALU tail
+        launch).  ``lead`` is 0 on purpose: a lead-in of zeros would do the same for the first outputs, but those are
+        the filter's start-up transient, |z| ~ 1e-7..1e-5 -- below the fixed-point kernel's 1e-5 absolute error, so
+        the NFM discriminator's phase there would be noise; the float32 VALU kernel keeps them (see ``submit``)."""
+        ksteps = -(-2 * decimation // 32)
+        return 0, 512 * ksteps + 34 * decimation
+
+    def submit(self, raw_dev, events=None, enclosing=None, lead_frames: int = 0) -> dict:
+        """Queue one capture (device tensor of interleaved frames, ``n_frames`` long).  Returns a ticket for ``collect``.
+        ``enclosing``/``lead_frames``: ``raw_dev`` is ``enclosing[2*lead_frames : 2*(lead_frames + n_frames)]``; frames
+        behind the capture may be read, ``lead_frames`` frames in front of it (if any) must be zeros
+        (see ``padded_capture_frames``)."""
         slot = self.slots[self._next % self.SLOTS]
         self._next += 1
         if slot["busy"] is not None:  # the slot's buffers are still owned by an earlier, uncollected capture
@@ -802,9 +862,10 @@ class ResidentCaptureRunner:
             with torch.cuda.stream(ps):
                 probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order)
         sign = self.override if self.override is not None else 1
-        ticket = self._chain(raw_dev, slot, sign, events)
+        halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        ticket = self._chain(raw_dev, slot, sign, events, halo)
         slot["tail_done"] = ticket["tail_done"]
-        ticket.update(probe=probe, sign=sign, raw=raw_dev)
+        ticket.update(probe=probe, sign=sign, raw=raw_dev, halo=halo)
         slot["busy"] = ticket
         return ticket
 
@@ -822,7 +883,7 @@ class ResidentCaptureRunner:
             if sign != ticket["sign"]:  # the speculation was wrong: this capture again, with the sign the probe chose
                 ticket["done"].synchronize()
                 probe, raw = ticket["probe"], ticket["raw"]
-                redo = self._chain(raw, slot, sign)
+                redo = self._chain(raw, slot, sign, None, ticket.get("halo"))
                 self._flush_egress()
                 slot["tail_done"] = redo["tail_done"]
                 ticket.update(redo, sign=sign, probe=probe, raw=raw)

@@ -499,6 +499,22 @@ def test_resident_capture_runner_batch_and_sign_speculation(A):
     ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
     assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
     assert abs(r["demod"].peak - want.audio_peak) < 1e-5
+    # the same capture inside a padded buffer (readable slack behind it; a lead-in of zeros is supported but not
+    # recommended, see padded_capture_frames): the last outputs come from the matrix-core kernel too
+    z_plain = runner.collect(runner.submit(devs[2]))["z"].clone()
+    lead, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    buf = torch.zeros(2 * (lead + n + slack), dtype=torch.int16, device=devs[2].device)
+    buf[2 * lead : 2 * (lead + n)] = devs[2]
+    buf[2 * (lead + n) :] = 12345  # the slack is read but must never matter
+    r = runner.collect(runner.submit(buf[2 * lead : 2 * (lead + n)], enclosing=buf, lead_frames=lead))
+    want = O.run_chain(caps[2], sample_rate=fs, freq_offset=f_off)
+    assert r["sign"] == 1 and r["z"].numel() == want.decimated.size
+    z_pad = r["z"].cpu().numpy()
+    assert rms(z_pad - want.decimated) < 2e-5 and np.abs(z_pad - want.decimated).max() < 1e-4
+    assert np.abs(z_pad[:200] - want.decimated[:200]).max() < 1e-4 and np.abs(z_pad[-200:] - want.decimated[-200:]).max() < 1e-4
+    assert float((r["z"] - z_plain).abs().max()) < 1e-4
+    ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+    assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
 
 
 def test_pipeline_cancel_removes_partial_output(A, tmp_path):
