@@ -127,8 +127,9 @@ typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
     int32_t reserved;          /* data-path variant + diagnostics flags.  0 = per-lane row loads; 64 = block-wide
                                 * contiguous LDS-DMA ring (needs iqa_mfma_ring_bytes(D) > 0 and a single k-step
-                                * range; LDS = ring + 8*(outputs_per_block+160); it keeps 256*S1 + S2 in one int32, so the
-                                * fragments must come from a quantisation that bounds it: dsp_plan.plan_mfma(acc32=True));
+                                * range; LDS = iqa_mfma_ring_bytes(D) whatever outputs_per_block is); 64|128 = the same with
+                                * 256*S1 + S2 kept in one int32, for fragments from a quantisation that bounds that sum:
+                                * dsp_plan.plan_mfma(acc32=True);
                                 * 4 / 4|8 = per-wave staged
                                 * variants; bits 0,1,4,5 are timing diagnostics, never set in production */
     double unit;               /* value of one tap LSB (ingest scale folded in) */

@@ -39,7 +39,7 @@ constexpr int RG_MAX_KS = 16;
 constexpr int RG_W = 512;      // sliding window of output sums (positions mod 512), per component
 constexpr int RG_GUARD = 64;   // a tile's scatter reaches at most 59 positions past its lane base: aliases of slots 0..63
 constexpr int RG_AS = RG_W + RG_GUARD;
-constexpr int RG_ACC_BYTES = 2 * RG_AS * 4;
+constexpr int RG_ACC_BYTES = 2 * RG_AS * 8;  // sized for the 64-bit sums; the 32-bit form uses half of it
 constexpr int RG_EMIT_WAVE = 2;  // (rt 2, parity 0): not an issuing wave
 // Parity-1 waves scatter a tile one round late (at the start of the next round, while their SIMD partner of parity 0
 // is already multiplying -- the two waves of a SIMD then alternate between the matrix pipe and the LDS instead of
@@ -60,7 +60,8 @@ __host__ __device__ constexpr int ring_rounds(int ks)
 
 struct RingCtx {
     char *smem;
-    int *s_acc;           // [Sre | Sim], RG_AS ints each: S = 256*S1 + S2 of output position p at slot p mod RG_W
+    int *s_acc;           // [Sre | Sim], RG_AS entries each, output position p at slot p mod RG_W.  ACC64: one int64
+                          // S1*2^32 + S2 per entry (16-bit taps, exact); else one int32 256*S1 + S2 (~14-bit taps)
     const char *stream0;  // this lane's source byte of chunk (rt & 1) of tile 0
     long long tile_bytes, i0, m0;
     int tiles, rounds, cnt, lane_off, rt, cp, col, h, lane;
@@ -72,24 +73,46 @@ struct RingEmit {
     double wc, ws;
 };
 
+template <bool ACC64>
 __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx &c, RingEmit &e, int k)
 {
     const int pos = 64 * k + 1 + c.lane;
     const int i = pos - MF_Q;  // output index inside the block
     const int s = pos & (RG_W - 1);
-    int *acc = c.s_acc;
-    int sr = acc[s], si = acc[RG_AS + s];
-    if (s < RG_GUARD) {
-        sr += acc[RG_W + s];
-        si += acc[RG_AS + RG_W + s];
-        acc[RG_W + s] = 0;
-        acc[RG_AS + RG_W + s] = 0;
+    double v_re, v_im;  // 256*S1 + S2 per component
+    if constexpr (ACC64) {
+        long long *acc = reinterpret_cast<long long *>(c.s_acc);
+        long long sr = acc[s], si = acc[RG_AS + s];
+        if (s < RG_GUARD) {
+            sr += acc[RG_W + s];
+            si += acc[RG_AS + RG_W + s];
+            acc[RG_W + s] = 0;
+            acc[RG_AS + RG_W + s] = 0;
+        }
+        acc[s] = 0;  // the slot is scattered into again 8 rounds from now
+        acc[RG_AS + s] = 0;
+        // the adds were (S1 << 32) + sign-extended S2: the low word is S2 itself (|S2| < 2^31), the rest is S1
+        const int s2r = static_cast<int>(sr), s2i = static_cast<int>(si);
+        const long long s1r = (sr - s2r) >> 32, s1i = (si - s2i) >> 32;
+        v_re = static_cast<double>(s1r) * 256.0 + static_cast<double>(s2r);
+        v_im = static_cast<double>(s1i) * 256.0 + static_cast<double>(s2i);
+    } else {
+        int *acc = c.s_acc;
+        int sr = acc[s], si = acc[RG_AS + s];
+        if (s < RG_GUARD) {
+            sr += acc[RG_W + s];
+            si += acc[RG_AS + RG_W + s];
+            acc[RG_W + s] = 0;
+            acc[RG_AS + RG_W + s] = 0;
+        }
+        acc[s] = 0;
+        acc[RG_AS + s] = 0;
+        v_re = static_cast<double>(sr);
+        v_im = static_cast<double>(si);
     }
-    acc[s] = 0;  // the slot is scattered into again 8 rounds from now
-    acc[RG_AS + s] = 0;
     if (i >= 0 && i < c.cnt) {
-        double d_re = (static_cast<double>(sr) * 256.0 + a.c_re) * a.unit;
-        double d_im = (static_cast<double>(si) * 256.0 + a.c_im) * a.unit;
+        double d_re = (v_re * 256.0 + a.c_re) * a.unit;
+        double d_im = (v_im * 256.0 + a.c_im) * a.unit;
         if (a.partial_in != nullptr) {
             const double2 pr = a.partial_in[c.i0 + i];
             d_re += pr.x;
@@ -138,7 +161,7 @@ __device__ __forceinline__ void ring_wait_and_barrier(int younger, int per_round
 // A loader wave (parity cp): per round, wait for its DMAs of this round, join the barrier, refill the slot the
 // previous round has left with the tile R-1 rounds ahead (all 2*KS chunks), and emit the group of 64 outputs that
 // became complete two rounds ago when that group's parity is its own.
-template <int KS, int DBG>
+template <int KS, int DBG, bool ACC64>
 __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 {
     constexpr int R = ring_rounds(KS);
@@ -177,7 +200,7 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
             // in order, so the adds of the tiles of round r-3 and earlier -- everything that reaches positions
             // <= 64 (r-2) -- have landed.
             asm volatile("" ::: "memory");
-            ring_emit_group(a2, c, em, r - RG_EMIT_LAG);
+            ring_emit_group<ACC64>(a2, c, em, r - RG_EMIT_LAG);
             asm volatile("" ::: "memory");
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
@@ -185,14 +208,14 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int k_last = (c.cnt + 62) >> 6;
     for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k)
-        if ((k & 1) == cp) ring_emit_group(a2, c, em, k);
+        if ((k & 1) == cp) ring_emit_group<ACC64>(a2, c, em, k);
 }
 
 // The main loop of a multiplying wave.  ISSUER (kernels without loader waves): this wave also feeds the ring
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ISSUER, bool EMIT, bool DEFER>
+template <int KS, int DBG, bool ACC64, bool ISSUER, bool EMIT, bool DEFER>
 __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
 {
     constexpr int R = ring_rounds(KS);
@@ -222,15 +245,28 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     // are in flight (it cannot tell the ring from the window), which would serialise the whole prefetch pipeline once
     // per round.  These adds touch the window only, never the ring.
     auto scatter = [&](int t, const v16i_t &acc1, const v16i_t &acc2) {
-        const unsigned p = lds_addr(c.s_acc + ((t * 32 + c.col + 4 * c.h + 1) & (RG_W - 1)) + (rt >> 1) * RG_AS + (rt & 1) * 32);
+        const int slot_idx = ((t * 32 + c.col + 4 * c.h + 1) & (RG_W - 1)) + (rt >> 1) * RG_AS + (rt & 1) * 32;
+        if constexpr (ACC64) {
+            // exact for 16-bit taps: ONE 64-bit add of (S1 << 32) + sign-extended S2 per element (3 dwords through the
+            // LDS data path instead of 2 x 2 for separate S1/S2 adds); the carry out of the low word is undone at emission
+            const unsigned p = lds_addr(reinterpret_cast<long long *>(c.s_acc) + slot_idx);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            // 256*S1 + S2 in ONE int32 (the host bounds the tap magnitudes so that this cannot overflow for any input,
-            // dsp_plan.plan_mfma(acc32=True)); the shift-add is a VALU op the compiler can see, so the MFMA -> VALU
-            // hazard distance is its business and the asm reads a VALU result
-            const int comb = (acc1[q] << 8) + acc2[q];
-            const int off = 4 * ((q & 3) + 8 * (q >> 2));
-            asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(p), "v"(comb), "n"(off));
+            for (int q = 0; q < 16; ++q) {
+                const long long comb = (static_cast<long long>(acc1[q]) << 32) + static_cast<long long>(acc2[q]);
+                const int off = 8 * ((q & 3) + 8 * (q >> 2));
+                asm volatile("ds_add_u64 %0, %1 offset:%2" ::"v"(p), "v"(comb), "n"(off));
+            }
+        } else {
+            const unsigned p = lds_addr(c.s_acc + slot_idx);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                // 256*S1 + S2 in ONE int32 (the host bounds the tap magnitudes so that this cannot overflow for any
+                // input, dsp_plan.plan_mfma(acc32=True)); the shift-add is a VALU op the compiler can see, so the
+                // MFMA -> VALU hazard distance is its business and the asm reads a VALU result
+                const int comb = (acc1[q] << 8) + acc2[q];
+                const int off = 4 * ((q & 3) + 8 * (q >> 2));
+                asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(p), "v"(comb), "n"(off));
+            }
         }
     };
     v16i_t held1 = zero16, held2 = zero16;  // DEFER: the previous tile's sums, scattered at the start of the next round
@@ -241,7 +277,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         else asm volatile("s_barrier" ::: "memory");
         if (EMIT && r >= RG_EMIT_LAG) {
             asm volatile("" ::: "memory");
-            ring_emit_group(a, c, em, r - RG_EMIT_LAG);  // see ring_loader for why these sums are final
+            ring_emit_group<ACC64>(a, c, em, r - RG_EMIT_LAG);  // see ring_loader for why these sums are final
             asm volatile("" ::: "memory");
         }
         if (DEFER && held_t >= 0) {
@@ -317,7 +353,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (EMIT) {
         const int k_last = (c.cnt + 62) >> 6;
-        for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k) ring_emit_group(a, c, em, k);
+        for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k) ring_emit_group<ACC64>(a, c, em, k);
     }
 }
 
@@ -326,7 +362,7 @@ constexpr int ring_threads() { return (RG_WAVES + (ring_has_loaders(KS) ? 2 : 0)
 
 // One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
 // stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
-template <int KS, int DBG>
+template <int KS, int DBG, bool ACC64>
 __global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) void k_channelize_mfma_s16_ring(MfmaArgs a)
 {
     constexpr int R = ring_rounds(KS);
@@ -350,7 +386,7 @@ __global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) v
     c.rounds = (c.tiles + 1) >> 1;
     c.smem = smem;
     c.s_acc = reinterpret_cast<int *>(smem + R * 2 * SLOT);
-    for (int i = tid; i < 2 * RG_AS; i += ring_threads<KS>()) c.s_acc[i] = 0;
+    for (int i = tid; i < RG_ACC_BYTES / 4; i += ring_threads<KS>()) c.s_acc[i] = 0;
 
     // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
     const long long row_bytes = 4LL * a.D;
@@ -363,7 +399,7 @@ __global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) v
         c.cp = wave - RG_WAVES;
         c.stream0 = stream;
         __syncthreads();
-        ring_loader<KS, DBG>(a, c);
+        ring_loader<KS, DBG, ACC64>(a, c);
         return;
     }
     // tap fragments of this wave's row tile: registers for the whole block
@@ -381,16 +417,16 @@ __global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) v
     __syncthreads();
     c.stream0 = stream + (c.rt & 1) * 1024;
     if (LOADERS) {
-        if (c.cp) ring_main<KS, DBG, false, false, true>(a, c, fq);
-        else ring_main<KS, DBG, false, false, false>(a, c, fq);
+        if (c.cp) ring_main<KS, DBG, ACC64, false, false, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, false, false, false>(a, c, fq);
     }
     // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
     else if ((c.rt >> 1) == c.cp) {
-        if (c.cp) ring_main<KS, DBG, true, false, true>(a, c, fq);
-        else ring_main<KS, DBG, true, false, false>(a, c, fq);
-    } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, false, true, false>(a, c, fq);
-    else if (c.cp) ring_main<KS, DBG, false, false, true>(a, c, fq);
-    else ring_main<KS, DBG, false, false, false>(a, c, fq);
+        if (c.cp) ring_main<KS, DBG, ACC64, true, false, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, true, false, false>(a, c, fq);
+    } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, false, true, false>(a, c, fq);
+    else if (c.cp) ring_main<KS, DBG, ACC64, false, false, true>(a, c, fq);
+    else ring_main<KS, DBG, ACC64, false, false, false>(a, c, fq);
 }
 
 bool mfma_ring_supported(int decimation)
@@ -401,33 +437,36 @@ bool mfma_ring_supported(int decimation)
 
 size_t mfma_ring_lds_bytes(int ksteps) { return static_cast<size_t>(ring_rounds(ksteps)) * 2 * 2048 * ksteps + RG_ACC_BYTES; }
 
-template <int KS, int DBG>
+template <int KS, int DBG, bool ACC64>
 static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_ring<KS, DBG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_ring<KS, DBG, ACC64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_channelize_mfma_s16_ring<KS, DBG>), dim3(blocks), dim3(ring_threads<KS>()), lds, stream, a);
+    hipLaunchKernelGGL((k_channelize_mfma_s16_ring<KS, DBG, ACC64>), dim3(blocks), dim3(ring_threads<KS>()), lds, stream, a);
 }
 
+// debug bit 7 (128) selects the 32-bit sums (needs fragments from dsp_plan.plan_mfma(acc32=True))
 void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
     const int dbg = a.debug & (1 | 16 | 32);
-    if (dbg && a.ksteps == 7) {  // diagnostic instantiations exist for the benchmark shape only
+    const bool acc64 = !(a.debug & 128);
+    if (dbg && a.ksteps == 7 && !acc64) {  // diagnostic instantiations exist for the benchmark shape only
         switch (dbg) {
-            case 1: return ring_launch_one<7, 1>(a, blocks, lds, stream);
-            case 16: return ring_launch_one<7, 16>(a, blocks, lds, stream);
-            case 17: return ring_launch_one<7, 17>(a, blocks, lds, stream);
-            case 32: return ring_launch_one<7, 32>(a, blocks, lds, stream);
-            case 33: return ring_launch_one<7, 33>(a, blocks, lds, stream);
+            case 1: return ring_launch_one<7, 1, false>(a, blocks, lds, stream);
+            case 16: return ring_launch_one<7, 16, false>(a, blocks, lds, stream);
+            case 17: return ring_launch_one<7, 17, false>(a, blocks, lds, stream);
+            case 32: return ring_launch_one<7, 32, false>(a, blocks, lds, stream);
+            case 33: return ring_launch_one<7, 33, false>(a, blocks, lds, stream);
             default: break;
         }
     }
     switch (a.ksteps) {
-#define RG_CASE(K) case K: return ring_launch_one<K, 0>(a, blocks, lds, stream)
+#define RG_CASE(K) \
+    case K: return acc64 ? ring_launch_one<K, 0, true>(a, blocks, lds, stream) : ring_launch_one<K, 0, false>(a, blocks, lds, stream)
         RG_CASE(1); RG_CASE(2); RG_CASE(3); RG_CASE(4); RG_CASE(5); RG_CASE(6); RG_CASE(7); RG_CASE(8);
         RG_CASE(9); RG_CASE(10); RG_CASE(11); RG_CASE(12); RG_CASE(13); RG_CASE(14); RG_CASE(15); RG_CASE(16);
 #undef RG_CASE

@@ -155,6 +155,11 @@ class _ChannelKernel:
     #: block streams its contiguous run of the capture through an LDS-DMA ring, tap fragments in registers;
     #: falls back to "plain" where it does not apply: D % 4 != 0, D > 256, multi-range passes)
     mfma_variant = "ring"
+    #: sums of the ring kernel: True (default) = one int32 256*S1 + S2 per output component with the tap unit enlarged
+    #: until that cannot overflow for any input (~14-bit taps, error ~1e-5 of full scale); False = one int64
+    #: (S1 << 32) + S2 with 16-bit taps -- the same integers as the per-lane kernel (~1e-6) -- at +10 % kernel time
+    #: (ds_add_u64 moves 3 dwords and takes two passes through the LDS banks).  Both are exact integer sums.
+    ring_acc32 = True
     _VARIANT = {"plain": (0, 0), "staged8": (4, 8 * 4 * 2048), "staged12": (4 | 8, 12 * 3 * 2048), "ring": (64, 0)}  # flags, LDS ring bytes
     mfma_min_outputs = 32768
 
@@ -182,7 +187,7 @@ class _ChannelKernel:
     def _ensure_mfma_locked(self):
         if self.mfma is None:
             ring = self.mfma_variant == "ring" and bool(self._ring_bytes) and -(-2 * self.plan.decimation // 32) <= P.MFMA_MAX_KSTEPS_PER_PASS
-            mp = P.plan_mfma(self.plan, acc32=ring)
+            mp = P.plan_mfma(self.plan, acc32=ring and self.ring_acc32)
             self.mfma = mp
             self.afrag_dev = [D.from_numpy(g.afrag.reshape(-1).view(np.uint8)) for g in mp.groups]
             self.mfma_params = []
@@ -196,7 +201,7 @@ class _ChannelKernel:
                 rng = self._range_max(ps.k_count, variant)
                 self._pass_variant = getattr(self, "_pass_variant", []) + [variant]
                 self.mfma_params.append(N.MfmaParams(
-                    outputs_per_block=rng, reserved=self._VARIANT[variant][0], unit=mp.groups[ps.group].unit, c_re=ps.c_re,
+                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.ring_acc32) else 0), unit=mp.groups[ps.group].unit, c_re=ps.c_re,
                     c_im=ps.c_im, debug_stamps=None, q_group=ps.group, k_first=ps.k_first, k_count=ps.k_count,
                     finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
@@ -314,7 +319,8 @@ def _cached_kernel(taps: np.ndarray, *, sample_rate: float, freq_offset: float, 
     taps = np.ascontiguousarray(taps)
     raw = taps.tobytes()
     key = (hash(raw), taps.dtype.str, taps.shape, float(sample_rate), float(freq_offset), int(mix_sign), int(decimation),
-           fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, D.torch_mod().cuda.current_device())
+           fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, _ChannelKernel.ring_acc32,
+           D.torch_mod().cuda.current_device())
     with _KERNEL_CACHE_LOCK:
         hit = _KERNEL_CACHE.get(key)
         if hit is not None and hit[0] == raw:

@@ -15,6 +15,7 @@ taps = A.design_channel_filter(fs, bw, d)
 z = D.empty(-(-n_total // d), "complex64")
 import os
 outs = {}
+PR._ChannelKernel.ring_acc32 = os.environ.get('ACC32', '1') == '1'  # the ablation instantiations exist for the int32 sums
 for dbg in [int(x) for x in os.environ.get('DBG', '0,4,12').split(',')]:
     PR._ChannelKernel.mfma_variant = {0: "plain", 4: "staged8", 12: "staged12", 64: "ring"}[dbg & 76]
     PR._KERNEL_CACHE.clear()
