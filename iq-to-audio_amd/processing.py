@@ -792,8 +792,9 @@ class ResidentCaptureRunner:
         gate.record()  # compute stream: behind this capture's probes, in front of its channelizer
         prev = self._egress_pending
         chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo)
-        self._ring_done = torch.cuda.Event()
-        self._ring_done.record()
+        if self.probe_stream is not None:
+            self._ring_done = torch.cuda.Event()
+            self._ring_done.record()
         if prev is not None:
             self._flush_egress(gate)  # the previous capture's D2H runs beside the channelizer, not beside the probes
         if self.tail is not self.compute:
