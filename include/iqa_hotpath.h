@@ -130,8 +130,7 @@ typedef struct {
                                 * range; LDS = iqa_mfma_ring_bytes(D) whatever outputs_per_block is); 64|128 = the same with
                                 * 256*S1 + S2 kept in one int32, for fragments from a quantisation that bounds that sum:
                                 * dsp_plan.plan_mfma(acc32=True);
-                                * 4 / 4|8 = per-wave staged
-                                * variants; bits 0,1,4,5 are timing diagnostics, never set in production */
+                                * bits 0,1,4,5 are timing diagnostics, never set in production */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
     void *debug_stamps;        /* NULL in production; diagnostics builds write per-wave cycle stamps here

@@ -201,222 +201,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_channelize_mfma_s16(MfmaArgs 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// LDS-staged variant.  Same arithmetic, different data path: instead of every lane loading 32 bytes of
-// its own row into VGPRs (64 separate L1 look-ups per wave-instruction, ~55 % TA busy), a wave copies
-// its tile's k-chunk -- 32 rows x 64 bytes -- into a PRIVATE 2 KiB LDS slot with two
-// global_load_lds_dwordx4 (LDS-DMA, no VGPRs): four consecutive lanes fetch the four 16-byte chunks of
-// one row's 64-byte segment, so a wave-instruction touches 16 segments instead of 64 rows.  The image
-// is XOR-swizzled on the SOURCE side (LDS-DMA writes base + lane*16 linearly): slot s of row r holds
-// chunk s ^ ((r>>2)&3), which makes the two ds_read_b128 of the MFMA lane (col, h) conflict-free.
-// A ring of ST_NB slots per wave keeps ST_NB-1 k steps of DMA in flight behind a hand-counted vmcnt
-// (the slots are private to the wave, so no barrier is involved).
-constexpr int ST_SLOT_BYTES = 2048;
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// WAVES: waves per block (one block per CU); ST_NB: ring depth; JIT_FRAGS: read each row tile's tap
-// fragments right before its MFMAs (8 live registers instead of 32) so that three waves fit per SIMD.
-template <int WAVES, int ST_NB, bool JIT_FRAGS>
-__global__ __launch_bounds__(WAVES *kWave, WAVES / 4) void k_channelize_mfma_s16_staged(MfmaArgs a)
-{
-    constexpr int THREADS = WAVES * kWave;
-    constexpr int ST_BYTES = WAVES * ST_NB * ST_SLOT_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = lane & 31, h = lane >> 5;
-
-    const long long i0 = static_cast<long long>(blockIdx.x) * a.range;
-    const int cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - i0));
-    const long long m0 = a.m_lo + i0;
-    const int tiles = (cnt + 63 + 31) >> 5;
-    const int acc_len = tiles * 32 + MF_Q + 4;
-
-    v4i_t *s_a = reinterpret_cast<v4i_t *>(smem);
-    char *s_stage = smem + static_cast<size_t>(a.ksteps) * MF_KSTEP_BYTES + wave * (ST_NB * ST_SLOT_BYTES);
-    int *s_acc = reinterpret_cast<int *>(smem + static_cast<size_t>(a.ksteps) * MF_KSTEP_BYTES + ST_BYTES);
-    {
-        const int n16 = a.ksteps * (MF_KSTEP_BYTES / 16);
-        for (int i0f = tid; i0f < n16; i0f += THREADS * 8) {
-            v4i_t tmp[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0f + u * THREADS;
-                tmp[u] = (i < n16) ? a.afrag[i] : v4i_t{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0f + u * THREADS;
-                if (i < n16) s_a[i] = tmp[u];
-            }
-        }
-    }
-    for (int i = tid; i < 4 * acc_len; i += THREADS) s_acc[i] = 0;
-    __syncthreads();
-
-    // producer role of this lane: row (lane>>2) [+16 for the second instruction], chunk (lane&3)^f(row)
-    const int drow = lane >> 2;
-    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);  // f(row) == f(row+16)
-    const long long row_bytes = static_cast<long long>(a.D) * 4;
-    const long long doff0 = drow * row_bytes + dchunk * 16;
-    const long long doff1 = doff0 + 16 * row_bytes;
-    // consumer role: MFMA lane (col, h) wants chunks 2h and 2h+1 of row `col`
-    const int f = (col >> 2) & 3;
-    const int rd0 = col * 64 + ((2 * h) ^ f) * 16;
-    const int rd1 = col * 64 + ((2 * h + 1) ^ f) * 16;
-
-    auto tile_base = [&](int tile) -> const char * {
-        const long long b0 = m0 - MF_Q - a.col_shift + static_cast<long long>(tile) * 32;  // first data row of the tile
-        return reinterpret_cast<const char *>(a.raw + (b0 * a.D + 1 - a.consumed) + 16 * a.k_first);
-    };
-    int pf_tile = wave, pf_ks = 0, pf_slot = 0;
-    const char *pf_base = tile_base(min(pf_tile, tiles - 1));
-    auto issue = [&]() {
-        const char *g = pf_base + pf_ks * 64;
-        char *dst = s_stage + pf_slot * ST_SLOT_BYTES;
-        __builtin_amdgcn_global_load_lds(g + doff0, (lds_void_t *)(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(g + doff1, (lds_void_t *)(dst + 1024), 16, 0, 0);
-        if (++pf_ks == a.ksteps) {
-            pf_ks = 0;
-            pf_tile += WAVES;
-            pf_base = tile_base(min(pf_tile, tiles - 1));  // past the end: re-read the last tile (in bounds, unused)
-        }
-        pf_slot = (pf_slot + 1 == ST_NB) ? 0 : pf_slot + 1;
-    };
-#pragma unroll
-    for (int s = 0; s < ST_NB; ++s) issue();
-
-    v4i_t fr[2 * MF_ROWTILES];
-    if constexpr (!JIT_FRAGS) {
-        const v4i_t *fa = s_a + lane;
-#pragma unroll
-        for (int i = 0; i < 2 * MF_ROWTILES; ++i) fr[i] = fa[i * 64];
-    }
-    v16i_t acc1[MF_ROWTILES], acc2[MF_ROWTILES];
-#pragma unroll
-    for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-        acc1[rt] = v16i_t{0};
-        acc2[rt] = v16i_t{0};
-    }
-    const v16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int cur_slot = 0;
-    const bool stamp = (a.debug & 2) && a.stamps != nullptr;  // diagnostics build path only
-    unsigned long long c_vm = 0, c_lds = 0, c_dma = 0, c_mfma = 0, c_sc = 0, tp = 0;
-#define ST_STAMP(ACC)                                                           \
-    if (stamp) {                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                      \
-        const unsigned long long tn = __builtin_amdgcn_s_memtime();             \
-        ACC += tn - tp;                                                         \
-        tp = tn;                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                      \
-    }
-    if (stamp) tp = __builtin_amdgcn_s_memtime();
-    for (int t = wave; t < tiles; t += WAVES) {
-        for (int ks = 0; ks < a.ksteps; ++ks) {
-            // the DMA pair of this step has landed once at most 2*(ST_NB-1) younger ones are outstanding
-            if constexpr (ST_NB == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (ST_NB == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            static_assert(ST_NB >= 2 && ST_NB <= 4, "vmcnt literals above are 2*(ST_NB-1)");
-            ST_STAMP(c_vm);
-            const char *sl = s_stage + cur_slot * ST_SLOT_BYTES;
-            const v4i_t d0 = *reinterpret_cast<const v4i_t *>(sl + rd0);
-            const v4i_t d1 = *reinterpret_cast<const v4i_t *>(sl + rd1);
-            v4i_t hi, lo;
-            hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
-            hi.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x07050301);
-            hi.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x07050301);
-            hi.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x07050301);
-            lo.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x06040200) ^ 0x80808080;
-            lo.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x06040200) ^ 0x80808080;
-            lo.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200) ^ 0x80808080;
-            lo.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x06040200) ^ 0x80808080;
-            // the slot has been read into registers (the byte split above waited for it): refill it
-            asm volatile("" ::"v"(hi), "v"(lo) : "memory");
-            ST_STAMP(c_lds);
-            if (!(a.debug & 16)) issue();  // bit 4: timing experiment without the data stream
-            ST_STAMP(c_dma);
-            cur_slot = (cur_slot + 1 == ST_NB) ? 0 : cur_slot + 1;
-            const int kn = (ks + 1 < a.ksteps) ? ks + 1 : 0;
-            const v4i_t *fa = s_a + kn * (MF_KSTEP_BYTES / 16) + lane;
-            if (a.debug & 32) {  // bit 5: timing experiment without the matrix work
-                asm volatile("" ::"v"(hi), "v"(lo));
-                ST_STAMP(c_mfma);
-                continue;
-            }
-            if constexpr (JIT_FRAGS) {
-                const v4i_t *fc = s_a + ks * (MF_KSTEP_BYTES / 16) + lane;
-                if (ks == 0) {
-#pragma unroll
-                    for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-                        const v4i_t q1 = fc[(2 * rt) * 64], q2 = fc[(2 * rt + 1) * 64];
-                        acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, hi, zero16, 0, 0, 0);
-                        acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, lo, zero16, 0, 0, 0);
-                        acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q2, hi, acc2[rt], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-                        const v4i_t q1 = fc[(2 * rt) * 64], q2 = fc[(2 * rt + 1) * 64];
-                        acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, hi, acc1[rt], 0, 0, 0);
-                        acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q1, lo, acc2[rt], 0, 0, 0);
-                        acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(q2, hi, acc2[rt], 0, 0, 0);
-                    }
-                }
-            } else if (ks == 0) {
-#pragma unroll
-                for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-                    acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], hi, zero16, 0, 0, 0);
-                    acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], lo, zero16, 0, 0, 0);
-                    acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt + 1], hi, acc2[rt], 0, 0, 0);
-                    fr[2 * rt] = fa[(2 * rt) * 64];
-                    fr[2 * rt + 1] = fa[(2 * rt + 1) * 64];
-                }
-            } else {
-#pragma unroll
-                for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-                    acc1[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], hi, acc1[rt], 0, 0, 0);
-                    acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt], lo, acc2[rt], 0, 0, 0);
-                    acc2[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr[2 * rt + 1], hi, acc2[rt], 0, 0, 0);
-                    fr[2 * rt] = fa[(2 * rt) * 64];
-                    fr[2 * rt + 1] = fa[(2 * rt + 1) * 64];
-                }
-            }
-            ST_STAMP(c_mfma);
-        }
-        if (a.debug & 1) {  // bit 0: timing experiment without the LDS scatter
-#pragma unroll
-            for (int rt = 0; rt < MF_ROWTILES; ++rt) asm volatile("" ::"v"(acc1[rt]), "v"(acc2[rt]));
-            continue;
-        }
-        int *base = s_acc + (t * 32 + col + 4 * h + 1);
-#pragma unroll
-        for (int rt = 0; rt < MF_ROWTILES; ++rt) {
-            int *p1 = base + (rt >> 1) * acc_len + (rt & 1) * 32;
-            int *p2 = p1 + 2 * acc_len;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                atomicAdd(p1 + off, acc1[rt][r]);
-                atomicAdd(p2 + off, acc2[rt][r]);
-            }
-        }
-        ST_STAMP(c_sc);
-    }
-#undef ST_STAMP
-    if (stamp && lane == 0) {
-        unsigned long long *o = a.stamps + (static_cast<size_t>(blockIdx.x) * WAVES + wave) * 8;
-        o[0] = c_vm;
-        o[1] = c_lds;
-        o[2] = c_dma;
-        o[3] = c_mfma;
-        o[4] = static_cast<unsigned long long>((tiles - wave + WAVES - 1) / WAVES);
-        o[5] = c_sc;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing (unused) DMAs before the LDS is reused
-    __syncthreads();
-    mfma_emit<THREADS>(a, s_acc, acc_len, cnt, i0, m0, tid);
-}
-
 }  // namespace iqa
 
 using namespace iqa;
@@ -475,10 +259,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         return fail_inval("MFMA channelizer range reads outside the block (use iqa_channelize for the edges)");
     const int64_t acc_len = full_tiles * 32 + MF_Q + 4;
     const bool ring = (q->reserved & 64) != 0;  // block-wide contiguous LDS-DMA ring (channelize_ring.hip)
-    const bool staged = !ring && (q->reserved & 4) != 0;
-    const bool waves12 = staged && (q->reserved & 8) != 0;  // 12-wave blocks (three waves per SIMD), ring of 3
-    const size_t st_bytes = staged ? (waves12 ? 12 * 3 : 8 * 4) * static_cast<size_t>(ST_SLOT_BYTES) : 0;
-    size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int) + st_bytes;
+    size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int);
     if (ring) {
         if (!mfma_ring_supported(static_cast<int>(D)) || k_first != 0 || ksteps != ksteps_all)
             return fail_inval("the ring kernel needs D % 4 == 0, D <= 256 and all k steps in one pass");
@@ -531,23 +312,9 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_staged<8, 4, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_staged<12, 3, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
-    }
-    if (staged) {
-        // the second DMA of a step reads 16 rows further than the per-lane loads of the plain kernel: same rows, checked above
-        if (waves12)
-            hipLaunchKernelGGL((k_channelize_mfma_s16_staged<12, 3, true>), dim3(static_cast<unsigned>(blocks)),
-                               dim3(12 * kWave), lds, as_stream(stream), a);
-        else
-            hipLaunchKernelGGL((k_channelize_mfma_s16_staged<8, 4, false>), dim3(static_cast<unsigned>(blocks)),
-                               dim3(MF_THREADS), lds, as_stream(stream), a);
-        return check_launch("k_channelize_mfma_s16_staged");
     }
     hipLaunchKernelGGL(k_channelize_mfma_s16, dim3(static_cast<unsigned>(blocks)), dim3(MF_THREADS), lds,
                        as_stream(stream), a);

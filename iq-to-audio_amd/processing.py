@@ -150,17 +150,16 @@ class _ChannelKernel:
 
     #: set to False to force the float32 VALU kernel everywhere (tests compare the two)
     use_mfma = True
-    #: data path of the MFMA kernel: "plain" (per-lane row loads into VGPRs), "staged8" (8 waves, LDS-DMA ring of 4),
-    #: "staged12" (12 waves = three per SIMD, ring of 3, tap fragments read just in time), "ring" (4 waves, the
-    #: block streams its contiguous run of the capture through an LDS-DMA ring, tap fragments in registers;
-    #: falls back to "plain" where it does not apply: D % 4 != 0, D > 256, multi-range passes)
+    #: data path of the MFMA kernel: "ring" (channelize_ring.hip: persistent blocks stream their contiguous run of the
+    #: capture through an LDS-DMA ring, tap fragments in registers; falls back to "plain" where it does not apply:
+    #: D % 4 != 0, D > 256, multi-range passes) or "plain" (channelize_mfma.hip: per-lane row loads into VGPRs)
     mfma_variant = "ring"
     #: sums of the ring kernel: True (default) = one int32 256*S1 + S2 per output component with the tap unit enlarged
     #: until that cannot overflow for any input (~14-bit taps, error ~1e-5 of full scale); False = one int64
     #: (S1 << 32) + S2 with 16-bit taps -- the same integers as the per-lane kernel (~1e-6) -- at +10 % kernel time
     #: (ds_add_u64 moves 3 dwords and takes two passes through the LDS banks).  Both are exact integer sums.
     ring_acc32 = True
-    _VARIANT = {"plain": (0, 0), "staged8": (4, 8 * 4 * 2048), "staged12": (4 | 8, 12 * 3 * 2048), "ring": (64, 0)}  # flags, LDS ring bytes
+    _VARIANT = {"plain": (0, 0), "ring": (64, 0)}  # flags, extra LDS bytes
     mfma_min_outputs = 32768
 
     def __init__(self, plan: P.ChannelPlan):

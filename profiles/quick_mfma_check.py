@@ -17,16 +17,16 @@ import os
 outs = {}
 PR._ChannelKernel.ring_acc32 = os.environ.get('ACC32', '1') == '1'  # the ablation instantiations exist for the int32 sums
 for dbg in [int(x) for x in os.environ.get('DBG', '0,4,12').split(',')]:
-    PR._ChannelKernel.mfma_variant = {0: "plain", 4: "staged8", 12: "staged12", 64: "ring"}[dbg & 76]
+    PR._ChannelKernel.mfma_variant = {0: "plain", 64: "ring"}[dbg & 64]
     PR._KERNEL_CACHE.clear()
     ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
-    ch.plan_ahead(); ch._kernel.mfma_params[0].reserved |= (dbg & ~76)
+    ch.plan_ahead(); ch._kernel.mfma_params[0].reserved |= (dbg & ~64)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for it in range(4):
         ch.consumed = 0; ch._hist = None
         ch.process(raw, out_dev=z, events=(e0, e1)); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-    if not (dbg & ~76): outs[dbg] = z.clone()
+    if not (dbg & ~64): outs[dbg] = z.clone()
     print(f"debug={dbg:3d} ({PR._ChannelKernel.mfma_variant}; skip: {'scatter ' if dbg&1 else ''}{'dma ' if dbg&16 else ''}{'mfma' if dbg&32 else ''}): kernel ms {[round(t,3) for t in ts]}")
 print('variants bitwise equal:', {k: bool(torch.equal(outs[k], list(outs.values())[0])) for k in outs}, 'max abs diff vs first:', {k: float((outs[k] - list(outs.values())[0]).abs().max()) for k in outs})
 if os.environ.get('NOSTAMPS'): sys.exit(0)
@@ -45,17 +45,3 @@ s = s[s[:, 4] > 0]
 print("outputs/block:", ch._kernel.mfma_params[0].outputs_per_block); print("waves:", len(s), "median cycles: prologue %d, loop %d (scatter %d), tail %d, tiles/wave %d" % tuple(np.median(s[:, i]) for i in range(5)))
 print("per tile: loop %.0f cycles, of which scatter %.0f; ideal MFMA per tile %d" % (np.median(s[:, 1] / s[:, 4]), np.median(s[:, 2] / s[:, 4]), 7 * 12 * 32))
 
-# staged kernel: where does a k step go?  (sums over all k steps of a wave; shares, not absolute time)
-PR._ChannelKernel.mfma_variant = os.environ.get('STAMPV', 'staged12')
-PR._KERNEL_CACHE.clear()
-ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
-ch.plan_ahead()
-st.zero_()
-ch._kernel.mfma_params[0].reserved |= 2
-ch._kernel.mfma_params[0].debug_stamps = st.data_ptr()
-ch.process(raw, out_dev=z); torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(-1, 8)
-s = s[s[:, 4] > 0]
-ksteps = 7
-per = lambda i: np.median(s[:, i] / (s[:, 4] * ksteps))
-print("staged kernel, cycles per k step per wave: wait-DMA %.0f | LDS read+split %.0f | DMA issue %.0f | 12 MFMA + 8 frag reads %.0f | scatter/7 %.0f" % (per(0), per(1), per(2), per(3), per(5)))

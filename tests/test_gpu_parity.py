@@ -647,32 +647,6 @@ def test_run_benchmark_contract(A, caplog):
         run_benchmark(seconds=1.0, sample_rate=2.5e6, freq_offset=2e6, center_freq=None, target_freq=None, base_kwargs=None)
 
 
-def test_mfma_variants_are_bit_identical(A):
-    """The three data paths of the MFMA kernel (per-lane row loads, LDS-DMA ring with 8 or 12 waves)
-    only differ in how the int16 rows reach the matrix cores: integer arithmetic -> identical bits."""
-    import torch
-
-    from iq_to_audio_amd import _dev as D
-    from iq_to_audio_amd import processing as PR
-
-    fs, d, n, f_off = 10e6, 104, 8_000_000, -1.3e6
-    raw = D.to_device(O.synth_capture_s16(fs, n / fs, 25e3).reshape(-1), "int16")
-    taps = A.design_channel_filter(fs, 12500.0, d)
-    old = (PR._ChannelKernel.mfma_variant, PR._ChannelKernel.mfma_min_outputs)
-    outs = {}
-    try:
-        PR._ChannelKernel.mfma_min_outputs = 4096
-        for v in ("plain", "staged8", "staged12"):
-            PR._ChannelKernel.mfma_variant = v
-            ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=-1, decimation=d, iq_order="qi")
-            outs[v] = ch.process(raw)
-            assert ch._kernel.last_kernel == "k_channelize_mfma_s16"
-    finally:
-        PR._ChannelKernel.mfma_variant, PR._ChannelKernel.mfma_min_outputs = old
-    assert torch.equal(outs["plain"], outs["staged8"]) and torch.equal(outs["plain"], outs["staged12"])
-
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize(
     "fs,d,bw,n",
