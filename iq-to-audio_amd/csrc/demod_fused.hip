@@ -220,17 +220,21 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
 {
     __shared__ Aff s_w[SC_THREADS / kWave];
     __shared__ float s_pk[SC_THREADS / kWave];
-    __shared__ double s_sq[SC_THREADS / kWave];
+    __shared__ double s_sq[2 * (SC_THREADS / kWave)];  // low | high part of a tile that straddles a chunk boundary
     __shared__ long long s_seg[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long blk0 = static_cast<long long>(blockIdx.x) * SC_TILE;
     const long long base = blk0 + static_cast<long long>(tid) * SC_ITEMS;
     const bool mr = (OP == F_AGC) && block_has_restart(a, blk0, blk0 + SC_TILE);
     const bool stats = (SINK == K_CLIP) && a.sumsq != nullptr && a.n_segs > 0;
-    if (stats && tid < 2) {
-        const long long idx = tid == 0 ? blk0 : min(blk0 + SC_TILE, a.n) - 1;
-        s_seg[tid] = lower_bound_ll(a.segs, a.n_segs, idx + 1) - 1;  // last start <= idx
-    }
+    // Issued first, consumed late: the state in front of this tile, and the segment (reference chunk) of the tile's
+    // first and last element, counted by the whole block in ONE round of loads (a two-thread binary search in front
+    // of the first barrier cost eight dependent global loads per block: two thirds of this kernel's time was waiting).
+    const double carry_in = a.carry[blockIdx.x];
+    // this thread's share of the chunk starts (one round of loads, issued in front of the tile's own loads)
+    long long seg_first = 0;
+    if (stats && tid < a.n_segs) seg_first = a.segs[tid];
+    if (stats && tid < 2) s_seg[tid] = -1;
     float u[SC_ITEMS], ub;
     load_u<OP, SRC>(a, base, u, ub);
     Aff m[SC_ITEMS];
@@ -240,6 +244,22 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
         m[i] = (base + i < a.n) ? fmap<OP>(a, base + i, u[i], i ? u[i - 1] : ub, mr) : Aff{1.0, 0.0};
         t = then(t, m[i]);
     }
+    if (stats) {
+        __syncthreads();  // s_seg initialised
+        const long long first = blk0, last = min(blk0 + SC_TILE, a.n) - 1;
+        int c0 = (tid < a.n_segs) && seg_first <= first, c1 = (tid < a.n_segs) && seg_first <= last;
+        for (long long kk = tid + SC_THREADS; kk < a.n_segs; kk += SC_THREADS) {
+            const long long st = a.segs[kk];
+            c0 += st <= first;
+            c1 += st <= last;
+        }
+        c0 = static_cast<int>(wave_sum(static_cast<float>(c0)));
+        c1 = static_cast<int>(wave_sum(static_cast<float>(c1)));
+        if (lane == 0 && (c0 | c1)) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[0]), static_cast<unsigned long long>(c0));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[1]), static_cast<unsigned long long>(c1));
+        }
+    }
     const Aff inc = wave_inclusive(t, lane);
     if (lane == kWave - 1) s_w[wave] = inc;
     __syncthreads();
@@ -248,13 +268,22 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
     Aff wpre{1.0, 0.0};
     for (int w = 0; w < wave; ++w) wpre = then(wpre, s_w[w]);
     ex = then(wpre, ex);
-    double s = fma(ex.A, a.carry[blockIdx.x], ex.B);
+    double s = fma(ex.A, carry_in, ex.B);
 
-    const bool uniform = stats && (s_seg[0] == s_seg[1]);
-    long long seg = stats ? s_seg[0] : -1;
-    if (stats && !uniform && base < a.n) seg = lower_bound_ll(a.segs, a.n_segs, base + 1) - 1;
+    // A tile (2048 samples) lies inside one reference chunk (`uniform`) or, a chunk being >= 40 k samples, straddles
+    // exactly one boundary (`simple`): the squares go to a low and a high running sum split at that boundary, reduced
+    // over the block, two atomics per block at most.  Only tiles with several boundaries (chunks shorter than a tile)
+    // take the general per-thread path with its own look-ups.
+    const long long seg0 = stats ? s_seg[0] : -1, seg1 = stats ? s_seg[1] : -1;
+    const bool uniform = stats && (seg0 == seg1);
+    const bool simple = stats && (seg1 == seg0 + 1);
+    const bool general = stats && !uniform && !simple;
+    long long bnd = a.n;  // first index of the high part
+    if (simple) bnd = a.segs[seg1];
+    long long seg = seg0;
+    if (general && base < a.n) seg = lower_bound_ll(a.segs, a.n_segs, base + 1) - 1;
     float pk = 0.f;
-    double run = 0.0;
+    double run = 0.0, run_hi = 0.0;
     float vout[SC_ITEMS];
 #pragma unroll
     for (int i = 0; i < SC_ITEMS; ++i) {
@@ -267,36 +296,33 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
                 pk = fmaxf(pk, fabsf(v));
                 vout[i] = fminf(fmaxf(v, -0.99f), 0.99f);
                 if (stats) {
-                    if (!uniform) {
+                    const double vv = static_cast<double>(v) * static_cast<double>(v);
+                    if (general) {
                         while (seg + 1 < a.n_segs && a.segs[seg + 1] <= idx) {
                             if (run != 0.0) atomicAdd(&a.sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
                             run = 0.0;
                             ++seg;
                         }
+                        run += vv;
+                    } else {
+                        run += idx < bnd ? vv : 0.0;
+                        run_hi += idx < bnd ? 0.0 : vv;
                     }
-                    run += static_cast<double>(v) * static_cast<double>(v);
                 }
             } else {
                 vout[i] = v;
             }
         }
     }
-    if (a.y_aligned && base + SC_ITEMS <= a.n) {  // 32 contiguous, aligned bytes per thread: two 16-byte stores
-        float4 *yp = reinterpret_cast<float4 *>(a.y + base);
-        yp[0] = make_float4(vout[0], vout[1], vout[2], vout[3]);
-        yp[1] = make_float4(vout[4], vout[5], vout[6], vout[7]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < SC_ITEMS; ++i)
-            if (base + i < a.n) a.y[base + i] = vout[i];
-    }
     if constexpr (SINK == K_CLIP) {
-        if (stats && !uniform && run != 0.0) atomicAdd(&a.sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
+        if (general && run != 0.0) atomicAdd(&a.sumsq[seg * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], run);
         pk = wave_max(pk);
-        const double wsq = uniform ? wave_sum(run) : 0.0;
+        const double wlo = (stats && !general) ? wave_sum(run) : 0.0;
+        const double whi = simple ? wave_sum(run_hi) : 0.0;
         if (lane == 0) {
             s_pk[wave] = pk;
-            s_sq[wave] = wsq;
+            s_sq[wave] = wlo;
+            s_sq[4 + wave] = whi;
         }
         __syncthreads();
         if (tid == 0) {
@@ -306,8 +332,20 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
                 const unsigned int m = __float_as_uint(fmaxf(fmaxf(s_pk[0], s_pk[1]), fmaxf(s_pk[2], s_pk[3])));
                 if (m > __hip_atomic_load(a.peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.peak_bits, m);
             }
-            if (uniform) atomicAdd(&a.sumsq[s_seg[0] * IQA_SUMSQ_SLOTS + (blockIdx.x & (IQA_SUMSQ_SLOTS - 1))], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
+            const int sub = blockIdx.x & (IQA_SUMSQ_SLOTS - 1);
+            if (stats && !general) atomicAdd(&a.sumsq[seg0 * IQA_SUMSQ_SLOTS + sub], s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
+            if (simple) atomicAdd(&a.sumsq[seg1 * IQA_SUMSQ_SLOTS + sub], s_sq[4] + s_sq[5] + s_sq[6] + s_sq[7]);
         }
+    }
+    // the audio goes out last: nothing waits for these stores (a barrier behind them would)
+    if (a.y_aligned && base + SC_ITEMS <= a.n) {  // 32 contiguous, aligned bytes per thread: two 16-byte stores
+        float4 *yp = reinterpret_cast<float4 *>(a.y + base);
+        yp[0] = make_float4(vout[0], vout[1], vout[2], vout[3]);
+        yp[1] = make_float4(vout[4], vout[5], vout[6], vout[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SC_ITEMS; ++i)
+            if (base + i < a.n) a.y[base + i] = vout[i];
     }
 }
 

@@ -29,3 +29,16 @@ for mode in ("nfm", "am", "usb"):
         print(f"demod {mode:4s} {label:10s}: {timeit(run):7.1f} us")
 rs = Resampler48k(fs_ch)
 print(f"resample: {timeit(lambda: rs.process(audio)):7.1f} us")
+
+# which part of the sink costs time: the same NFM call with the peak and/or the per-chunk sums switched off
+from ctypes import byref, c_int64, c_void_p
+from iq_to_audio_amd import _native as N
+dem = ChannelDemod("nfm", fs_ch, deemph_us=300.0, agc_enabled=True)
+dem.prepare(n, starts)
+_, _, starts_dev, sumsq, work, scratch = dem._prepared
+for pk, ss in ((1, 1), (0, 1), (1, 0), (0, 0)):
+    def run():
+        N.call("iqa_demodulate", byref(dem.params), N.ptr(z), c_int64(n), N.ptr(dem.state_dev), N.ptr(starts_dev) if ss else c_void_p(0),
+               c_int64(len(starts) if ss else 0), N.ptr(dem.peak_dev) if pk else c_void_p(0), N.ptr(sumsq) if ss else c_void_p(0),
+               N.ptr(audio), N.ptr(scratch), N.ptr(work), N.stream_ptr())
+    print(f"nfm peak={pk} sums={ss}: {timeit(run):7.1f} us")
