@@ -854,15 +854,16 @@ class ResidentCaptureRunner:
         if slot["busy"] is not None:  # the slot's buffers are still owned by an earlier, uncollected capture
             self.collect(slot["busy"])
         torch = D.torch_mod()
-        if slot.get("tail_done") is not None:
+        if slot.get("tail_done") is not None and self.tail != torch.cuda.current_stream():
             torch.cuda.current_stream().wait_event(slot["tail_done"])  # z/audio of this slot are free again
         probe = None
         if self.override is None:
             warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
-            ready = torch.cuda.Event()
-            ready.record()
             ps = self.probe_stream if self.probe_stream is not None else self.tail
-            ps.wait_event(ready)  # raw_dev was produced on the caller's stream
+            if ps != torch.cuda.current_stream():  # raw_dev was produced on the caller's stream
+                ready = torch.cuda.Event()
+                ready.record()
+                ps.wait_event(ready)
             if self.probe_stream is not None and self._ring_done is not None:
                 ps.wait_event(self._ring_done)
             with torch.cuda.stream(ps):
