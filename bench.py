@@ -9,7 +9,7 @@ effective 4 194 304, D = 104, 6401 taps).
 One *step* = one pass of the whole hot path over the capture:
   mixer-sign probe -> fused ingest+mix+FIR+decimate -> discriminator -> de-emphasis scan ->
   peak/clip -> 48 kHz polyphase resample -> PCM16 -> D2H of the audio [-> RCCL gather at N>1].
-Steps are queued through processing.ResidentCaptureRunner (a batch of captures with one set of settings):
+Steps are queued through batch.ResidentCaptureRunner (a batch of captures with one set of settings):
 no host<->device synchronisation inside a step, the channelizer runs speculatively for mixer sign +1
 behind the probes (checked when the capture is collected), and the D2H of one capture overlaps the
 kernels of the next.
@@ -61,7 +61,7 @@ def main() -> None:
     from iq_to_audio_amd import _dev as D
     from iq_to_audio_amd import dsp_plan as P
     from iq_to_audio_amd.benchmark import synthetic_iq_s16
-    from iq_to_audio_amd.processing import ResidentCaptureRunner
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

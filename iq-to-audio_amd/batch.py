@@ -1,0 +1,194 @@
+"""Batches of captures that already sit in HBM: :class:`ResidentCaptureRunner`.
+
+The per-chunk loop of the reference's ``ProcessingPipeline.run`` (processing.py:1070-1154) plus the writer's 48 kHz leg,
+for whole device-resident captures with one set of settings (the ``--benchmark`` pattern, multi-file batches;
+``bench.py`` is a loop over it).  Everything here is host-side sequencing of the stages in :mod:`.processing`:
+streams, events, buffer slots -- no arithmetic.
+"""
+from __future__ import annotations
+
+from ctypes import c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from . import _dev as D
+from . import _native as N
+from . import dsp_plan as P
+from .processing import ChannelDemod, Channelizer, MixSignProbe, Resampler48k
+
+
+class ResidentCaptureRunner:
+    """Ingest -> 48 kHz PCM16 for whole captures that already sit in HBM (multi-file batches with one set of
+    settings; ``bench.py``): the per-chunk loop of the reference (processing.py:1070-1154) plus the writer's
+    ``-ar 48000 pcm_s16le`` leg for one capture per ``submit`` -- queued without any host<->device
+    synchronisation, so consecutive captures overlap on the GPU:
+
+    * the two mixer-sign probes (``choose_mix_sign``, processing.py:623-663) and, right behind them, the
+      channelizer run *speculatively* for sign +1 -- the reference's tie-break and the common case (a signal
+      at +f_off lands at DC with sign +1) -- then demodulator + writer clip + 48 kHz
+      resample + PCM16;
+    * egress stream: D2H of the PCM16 into pinned memory (and whatever the caller chains on ``done``),
+      beside the next capture's kernels.
+
+    ``collect`` waits for a capture, reads the probe back and, if it chose -1 after all, re-runs that capture
+    with the right sign before returning.  Nothing is cached between captures except the plans.
+    """
+
+    SLOTS = 2
+
+    def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
+                 chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
+                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, tail_stream: bool = False, probe_stream: bool = False):
+        torch = D.torch_mod()
+        self.taps, self.fs, self.f_off, self.d, self.fs_ch = np.asarray(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
+        self.chunk, self.n_frames, self.fmt, self.iq_order = int(chunk), int(n_frames), fmt, iq_order
+        self.demod_args = dict(mode=demod_mode, deemph_us=deemph_us, agc_enabled=agc_enabled)
+        self.override = mix_sign_override if mix_sign_override in (1, -1) else None
+        self.n_dec = -(-self.n_frames // self.d)
+        self.starts = P.chunk_output_starts(self.chunk, self.d, 0, self.n_frames)
+        self.rs = Resampler48k(self.fs_ch)
+        self.n48 = self.rs.plan.n_out(self.n_dec)
+        self.compute = torch.cuda.current_stream()
+        # tail_stream=True puts demod/resample/PCM16 and the probes on a second stream.  Measured on MI355X it buys
+        # ~6 % per capture at best while stretching the channelizer by 40 % (the small kernels steal its CU slots),
+        # so the default keeps one compute stream; only the D2H runs beside it.
+        self.tail = torch.cuda.Stream() if tail_stream else self.compute
+        self.egress = torch.cuda.Stream()
+        # probe_stream=True runs the probes (off the critical path: the channelizer is speculative) on their own stream,
+        # gated to start when the previous capture's channelizer has finished.  Measured: no gain -- whatever part of
+        # them is caught beside the next channelizer is starved and stretches it by 10 % -- so it is off by default.
+        self.probe_stream = torch.cuda.Stream() if probe_stream else None
+        self._ring_done = None
+        self.slots = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
+                           pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(), busy=None,
+                           dem=ChannelDemod(demod_mode, self.fs_ch, deemph_us=deemph_us, agc_enabled=agc_enabled))
+                      for _ in range(self.SLOTS)]
+        self._next = 0
+        self._egress_pending = None  # ticket whose D2H has not been queued yet (see _flush_egress)
+        self.egress_workgroups = 8
+
+    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None):
+        """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
+        torch = D.torch_mod()
+        chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
+                           fmt=self.fmt, iq_order=self.iq_order)
+        chan.plan_ahead()
+        dem = slot["dem"]
+        with torch.cuda.stream(self.tail):
+            dem.reset()
+            dem.prepare(self.n_dec, self.starts)
+        gate = torch.cuda.Event()
+        gate.record()  # compute stream: behind this capture's probes, in front of its channelizer
+        prev = self._egress_pending
+        chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo)
+        if self.probe_stream is not None:
+            self._ring_done = torch.cuda.Event()
+            self._ring_done.record()
+        if prev is not None:
+            self._flush_egress(gate)  # the previous capture's D2H runs beside the channelizer, not beside the probes
+        if self.tail is not self.compute:
+            z_ready = torch.cuda.Event()
+            z_ready.record()
+            self.tail.wait_event(z_ready)
+        with torch.cuda.stream(self.tail):
+            dem.process(slot["z"], self.starts, slot["audio"])
+            y48 = self.rs.process(slot["audio"])
+            pcm = self.rs.to_pcm16(y48)
+            tail_done = torch.cuda.Event()
+            tail_done.record()
+        done = torch.cuda.Event()
+        ticket = dict(chan=chan, dem=dem, pcm=pcm, y48=y48, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel,
+                      slot=slot, egress_queued=False)
+        self._egress_pending = ticket
+        return ticket
+
+    def _flush_egress(self, gate=None) -> None:
+        """Queue the D2H of the capture whose PCM16 is ready (or will be, behind its tail_done event).  Called right
+        before the next capture's channelizer is launched, gated on an event behind that capture's probes, so the
+        copy kernel -- whose waves sit on PCIe stores -- shares the GPU with the long HBM-bound kernel instead of the
+        small latency-bound ones (measured: a probe beside the copy takes 120 us instead of 20); from ``collect``,
+        ungated, for the last capture of a batch."""
+        t = self._egress_pending
+        if t is None or t["egress_queued"]:
+            return
+        torch = D.torch_mod()
+        self.egress.wait_event(t["tail_done"])
+        if gate is not None:
+            self.egress.wait_event(gate)
+        with torch.cuda.stream(self.egress):
+            t["pcm"].record_stream(self.egress)
+            host = t["slot"]["pcm_host"]
+            N.call("iqa_trickle_copy", N.ptr(t["pcm"]), c_void_p(host.data_ptr()), c_int64(host.numel() * host.element_size()),
+                   c_int32(self.egress_workgroups), N.stream_ptr())
+            t["done"].record()
+        t["egress_queued"] = True
+        self._egress_pending = None
+
+    @staticmethod
+    def padded_capture_frames(decimation: int, ntaps: int) -> tuple[int, int]:
+        """(lead, slack) frames a capture buffer should carry in front of / behind the capture: ``slack`` readable
+        (ignored) frames behind it make the LAST outputs interior outputs of the matrix-core channelizer (no VALU tail
+        launch).  ``lead`` is 0 on purpose: a lead-in of zeros would do the same for the first outputs, but those are
+        the filter's start-up transient, |z| ~ 1e-7..1e-5 -- below the fixed-point kernel's 1e-5 absolute error, so
+        the NFM discriminator's phase there would be noise; the float32 VALU kernel keeps them (see ``submit``)."""
+        ksteps = -(-2 * decimation // 32)
+        return 0, 512 * ksteps + 34 * decimation
+
+    def submit(self, raw_dev, events=None, enclosing=None, lead_frames: int = 0) -> dict:
+        """Queue one capture (device tensor of interleaved frames, ``n_frames`` long).  Returns a ticket for ``collect``.
+        ``enclosing``/``lead_frames``: ``raw_dev`` is ``enclosing[2*lead_frames : 2*(lead_frames + n_frames)]``; frames
+        behind the capture may be read, ``lead_frames`` frames in front of it (if any) must be zeros
+        (see ``padded_capture_frames``)."""
+        slot = self.slots[self._next % self.SLOTS]
+        self._next += 1
+        if slot["busy"] is not None:  # the slot's buffers are still owned by an earlier, uncollected capture
+            self.collect(slot["busy"])
+        torch = D.torch_mod()
+        if slot.get("tail_done") is not None and self.tail != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_event(slot["tail_done"])  # z/audio of this slot are free again
+        probe = None
+        if self.override is None:
+            warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
+            ps = self.probe_stream if self.probe_stream is not None else self.tail
+            if ps != torch.cuda.current_stream():  # raw_dev was produced on the caller's stream
+                ready = torch.cuda.Event()
+                ready.record()
+                ps.wait_event(ready)
+            if self.probe_stream is not None and self._ring_done is not None:
+                ps.wait_event(self._ring_done)
+            with torch.cuda.stream(ps):
+                probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order)
+        sign = self.override if self.override is not None else 1
+        halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        ticket = self._chain(raw_dev, slot, sign, events, halo)
+        slot["tail_done"] = ticket["tail_done"]
+        ticket.update(probe=probe, sign=sign, raw=raw_dev, halo=halo)
+        slot["busy"] = ticket
+        return ticket
+
+    def collect(self, ticket: dict) -> dict:
+        """Wait for a submitted capture.  Returns {"pcm_host", "sign", "demod" (``.peak``, ``.chunk_rms_dbfs()``),
+        "audio", "z", "kernel"}; the buffers belong to the runner and are reused ``SLOTS`` submits later."""
+        slot = ticket["slot"]
+        if ticket.get("collected"):
+            return ticket["result"]
+        sign = ticket["sign"]
+        if self._egress_pending is ticket:
+            self._flush_egress()
+        if ticket["probe"] is not None:
+            sign = ticket["probe"].result()
+            if sign != ticket["sign"]:  # the speculation was wrong: this capture again, with the sign the probe chose
+                ticket["done"].synchronize()
+                probe, raw = ticket["probe"], ticket["raw"]
+                redo = self._chain(raw, slot, sign, None, ticket.get("halo"))
+                self._flush_egress()
+                slot["tail_done"] = redo["tail_done"]
+                ticket.update(redo, sign=sign, probe=probe, raw=raw)
+        ticket["done"].synchronize()
+        ticket["collected"] = True
+        ticket["raw"] = ticket["pcm"] = ticket["y48"] = None  # back to the allocator: the next capture reuses them
+        if slot["busy"] is ticket:
+            slot["busy"] = None
+        ticket["result"] = dict(pcm_host=slot["pcm_host"], sign=int(sign), audio=slot["audio"], z=slot["z"],
+                                kernel=ticket["kernel"], demod=ticket["dem"], done=ticket["done"])
+        return ticket["result"]

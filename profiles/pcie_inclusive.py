@@ -8,7 +8,7 @@ import numpy as np, torch
 import iq_to_audio_amd as A
 from iq_to_audio_amd import _dev as D, dsp_plan as P
 from iq_to_audio_amd.benchmark import synthetic_iq_s16
-from iq_to_audio_amd.processing import ResidentCaptureRunner
+from iq_to_audio_amd.batch import ResidentCaptureRunner
 
 fs, f_off, n_total = 10e6, 25e3, 600_000_000
 d, fs_ch = P.choose_decimation(fs, 96000.0); chunk = P.tune_chunk_size(fs, 1048576)

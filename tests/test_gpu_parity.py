@@ -452,7 +452,7 @@ def test_pipeline_end_to_end_wav(A, tmp_path):
 
 
 def test_resident_capture_runner_batch_and_sign_speculation(A):
-    """processing.ResidentCaptureRunner: a batch of device-resident captures with one set of settings, every
+    """batch.ResidentCaptureRunner: a batch of device-resident captures with one set of settings, every
     capture queued without a host sync (speculative mixer sign +1, tail on a second stream).  Each capture's
     48 kHz PCM16 must equal the oracle's (<= 1 LSB), captures must not bleed into each other through the two
     buffer slots, and a capture whose probe picks sign -1 must come out as if the sign had been known."""
@@ -460,7 +460,7 @@ def test_resident_capture_runner_batch_and_sign_speculation(A):
 
     from iq_to_audio_amd import _dev as D
     from iq_to_audio_amd import dsp_plan as P
-    from iq_to_audio_amd.processing import ResidentCaptureRunner
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
 
     fs, f_off, secs = 10e6, 25e3, 0.9
     d, fs_ch = P.choose_decimation(fs, 96_000.0)
@@ -515,6 +515,40 @@ def test_resident_capture_runner_batch_and_sign_speculation(A):
     assert float((r["z"] - z_plain).abs().max()) < 1e-4
     ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
     assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
+
+
+@pytest.mark.parametrize("mode,agc,fs,bw", [("am", True, 10e6, 10_000.0), ("usb", False, 20e6, 2_800.0), ("nfm", True, 5e6, 12_500.0)])
+def test_resident_capture_runner_other_modes_and_rates(A, mode, agc, fs, bw):
+    """The batch path for the other demodulators and capture shapes: AM at the C2 rate, USB (AGC off: the AGC case is
+    ill-conditioned in the reference itself) on the C3 narrow filter (32769 taps, three tap-row groups
+    chained through partial sums), NFM at 5 MS/s (D = 52: four k steps).  48 kHz PCM16 within 1 LSB of the oracle's."""
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
+
+    f_off, secs = 25e3, 0.45
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    chunk = P.tune_chunk_size(fs, 1_048_576)
+    taps = A.design_channel_filter(fs, bw, d)
+    n = int(round(fs * secs))
+    cap = O.synth_capture_s16(fs, secs, f_off, seed=7)
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
+                                   n_frames=n, demod_mode=mode, agc_enabled=agc)
+    _, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    import torch
+
+    buf = torch.zeros(2 * (n + slack), dtype=torch.int16, device=D.device())
+    buf[: 2 * n] = D.to_device(cap.reshape(-1), "int16")
+    r = runner.collect(runner.submit(buf[: 2 * n], enclosing=buf, lead_frames=0))
+    want = O.run_chain(cap, sample_rate=fs, freq_offset=f_off, bandwidth=bw, demod_mode=mode, agc_enabled=agc,
+                       keep_decimated=False)
+    assert r["sign"] == want.mix_sign and r["kernel"] == "k_channelize_mfma_s16_ring"
+    audio = r["audio"].cpu().numpy()
+    assert audio.size == want.audio.size and rms(audio - want.audio) < 5e-5
+    ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+    pcm = r["pcm_host"].numpy()
+    assert pcm.size == ref48.size and np.max(np.abs(pcm.astype(np.int32) - ref48.astype(np.int32))) <= 2
+    assert abs(r["demod"].peak - want.audio_peak) < 1e-4
 
 
 def test_pipeline_cancel_removes_partial_output(A, tmp_path):
