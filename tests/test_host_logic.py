@@ -327,3 +327,52 @@ def test_cli_argument_surface():
         with pytest.raises(SystemExit) as exc:
             cli.main(bad)
         assert exc.value.code == 2
+
+
+@pytest.mark.parametrize("fs,bw,d", [(10e6, 12_500.0, 104), (20e6, 12_500.0, 208), (20e6, 2_800.0, 208), (5e6, 12_500.0, 52)])
+def test_mfma_plan_quantisation_is_exact_and_overflow_proof(fs, bw, d):
+    """dsp_plan.plan_mfma: T = 256*q1 + q2 with both bytes signed reproduces the quantised taps exactly, the per-pass
+    constants are 128*sum(T), and with acc32 (the ring kernel's one-int32 sums) the worst case over ALL int16 inputs,
+    sum 128*(257|q1| + |q2|) over the rows of a component, stays below 2^31 while the unit grows by at most 32x
+    (2-3 bits of tap resolution for the 12.5 kHz filters, 4-5 for the side groups of the 32769-tap one) over the 16-bit plan."""
+    taps = P.design_channel_filter(fs, bw, d)
+    lpad = -(-len(taps) // 256) * 256
+    plan = P.plan_channel(taps, sample_rate=fs, freq_offset=0.113 * fs, mix_sign=1, decimation=d, fmt="s16", iq_order="iq",
+                          padded_len=lpad)
+    full, tight = P.plan_mfma(plan), P.plan_mfma(plan, acc32=True)
+    assert len(full.groups) == len(tight.groups) == max(1, -(-(-(-len(taps) // d)) // P.MFMA_Q))
+    for gf, gt in zip(full.groups, tight.groups):
+        for g in (gf, gt):
+            frag = g.afrag.astype(np.int64)  # [kstep][rowtile][piece][lane][16]
+            q1, q2 = frag[:, :, 0], frag[:, :, 1]
+            assert np.abs(q1).max() <= 127 and q2.min() >= -128 and q2.max() <= 127
+            # undo the fragment order: lane l holds row l&31, k = 16*(l>>5) + j of its row tile / k step
+            t = (256 * q1 + q2).reshape(q1.shape[0], 4, 2, 32, 16).transpose(1, 3, 0, 2, 4).reshape(128, -1)
+            np.testing.assert_array_equal(t, g.tq)
+        for comp in (slice(0, 64), slice(64, 128)):
+            q2t = ((gt.tq[comp] + 128) & 255) - 128
+            q1t = (gt.tq[comp] - q2t) >> 8
+            assert int((128 * (257 * np.abs(q1t).astype(np.int64) + np.abs(q2t))).sum()) < 2**31 - 1
+        assert gf.unit <= gt.unit <= 32 * gf.unit
+    for ps in tight.passes:
+        sl = tight.groups[ps.group].tq[:, 32 * ps.k_first : 32 * (ps.k_first + ps.k_count)]
+        assert ps.c_re == 128.0 * float(sl[:64].sum()) and ps.c_im == 128.0 * float(sl[64:].sum())
+
+
+def test_mfma_interior_with_lead_in_and_slack():
+    """dsp_plan.mfma_interior: the outputs whose whole matrix-core read range lies inside the block.  A negative
+    `consumed` (a lead-in of zeros in front of frame 0) moves the first interior output down to 0, readable slack
+    behind the block moves the last one up to the block's last output; without either the head needs the 64 tap rows
+    of history and the tail the K padding plus 30 columns of tile rounding."""
+    d, ks, n = 104, 7, 600_000_000
+    n_out = -(-n // d)
+    m_a, m_b = P.mfma_interior(0, n, 0, n_out, d, ks)
+    assert m_a == 64 and n_out - 40 <= m_b < n_out
+    assert (m_b + 29) * d + 1 + 16 * ks <= n  # last column read stays inside the block
+    m_a2, m_b2 = P.mfma_interior(-(66 * d), n + 66 * d + 8192, 0, n_out, d, ks)
+    assert (m_a2, m_b2) == (0, n_out)
+    # a streamed block in the middle of a capture: history comes from the previous block
+    m_a3, _ = P.mfma_interior(1_000_000, 4_194_304, -(-1_000_000 // d), 40_330, d, ks)
+    assert (m_a3 - 64) * d + 1 >= 1_000_000
+    # three tap-row groups (32769 taps at D = 208): the read range starts 192 rows back
+    assert P.mfma_interior(0, 10_000_000, 0, 48_077, 208, 13, 3)[0] == 192
