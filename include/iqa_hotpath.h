@@ -148,6 +148,11 @@ int64_t iqa_mfma_afrag_bytes(int32_t decimation);
  * contiguous bytes, so the last output of a ring pass must satisfy
  * (m_last - 1)*D + 512*ceil(2D/32) < consumed + n_frames. */
 int64_t iqa_mfma_ring_bytes(int32_t decimation);
+/* Which ring kernel covers a pass over k steps [k_first, k_first + k_count) at this decimation: 0 = none (use the
+ * per-lane kernel, reserved = 0), 1 = contiguous slots (all k steps in one pass, D % 4 == 0, D <= 256), 2 = row-staged
+ * slots (any D, k_count <= 11, int32 sums only: acc32 != 0).  Mode 2 reads exactly the frames the per-lane kernel
+ * reads; mode 1 needs the slack described above. */
+int32_t iqa_mfma_ring_mode(int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32);
 int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,
                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first, int64_t n_out,
                         void *z_out_dev, void *stream);

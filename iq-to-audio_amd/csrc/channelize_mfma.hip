@@ -207,9 +207,15 @@ using namespace iqa;
 
 extern "C" int64_t iqa_mfma_ring_bytes(int32_t decimation)
 {
-    // LDS bytes of the ring kernel's data ring for this decimation, or 0 when the ring kernel does not apply
+    // LDS bytes of a ring-kernel block with contiguous slots for this decimation, or 0 when that form does not apply
     if (decimation < 1 || !mfma_ring_supported(decimation)) return 0;
-    return static_cast<int64_t>(mfma_ring_lds_bytes((2 * decimation + 31) / 32));
+    return static_cast<int64_t>(mfma_ring_lds_bytes((2 * decimation + 31) / 32, false));
+}
+
+extern "C" int32_t iqa_mfma_ring_mode(int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32)
+{
+    if (decimation < 1) return 0;
+    return mfma_ring_mode(decimation, k_first, k_count, acc32 == 0);
 }
 
 extern "C" int64_t iqa_mfma_afrag_bytes(int32_t decimation)
@@ -260,16 +266,20 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     const int64_t acc_len = full_tiles * 32 + MF_Q + 4;
     const bool ring = (q->reserved & 64) != 0;  // block-wide contiguous LDS-DMA ring (channelize_ring.hip)
     size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int);
+    int ring_mode = 0;
     if (ring) {
-        if (!mfma_ring_supported(static_cast<int>(D)) || k_first != 0 || ksteps != ksteps_all)
-            return fail_inval("the ring kernel needs D % 4 == 0, D <= 256 and all k steps in one pass");
-        // a slot is filled in whole 1 KiB chunks: every tile reads 2048*ksteps bytes from its first frame
-        const int64_t slot_frames = 512LL * ksteps;
-        const int64_t t_last = m_first + (blocks - 1) * range - MF_Q - col_shift + (last_tiles - 1) * 32;
-        const int64_t t_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q - col_shift + (full_tiles - 1) * 32 : t_last;
-        if (t_last * D + 1 - consumed + slot_frames > n_frames || t_full * D + 1 - consumed + slot_frames > n_frames)
-            return fail_inval("ring kernel range reads outside the block (use iqa_channelize for the edges)");
-        lds = mfma_ring_lds_bytes(ksteps);  // ring + sliding window: independent of outputs_per_block
+        ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, !(q->reserved & 128));
+        if (ring_mode == 0)
+            return fail_inval("the ring kernel does not cover this (decimation, k-step range, sum width): see iqa_mfma_ring_mode");
+        if (ring_mode == 1) {
+            // a contiguous slot is filled in whole 1 KiB chunks: every tile reads 2048*ksteps bytes from its first frame
+            const int64_t slot_frames = 512LL * ksteps;
+            const int64_t t_last = m_first + (blocks - 1) * range - MF_Q - col_shift + (last_tiles - 1) * 32;
+            const int64_t t_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q - col_shift + (full_tiles - 1) * 32 : t_last;
+            if (t_last * D + 1 - consumed + slot_frames > n_frames || t_full * D + 1 - consumed + slot_frames > n_frames)
+                return fail_inval("ring kernel range reads outside the block (use iqa_channelize for the edges)");
+        }  // row-staged slots read exactly what the per-lane kernel reads: covered by the checks above
+        lds = mfma_ring_lds_bytes(ksteps, ring_mode == 2);  // ring + sliding window: independent of outputs_per_block
     }
     if (lds > 160 * 1024) return fail_inval("tap fragments + accumulators exceed 160 KiB of LDS");
 
@@ -307,7 +317,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
     if (ring) {
-        mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream));
+        mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2);
         return check_launch("k_channelize_mfma_s16_ring");
     }
     static bool attr_set = false;

@@ -22,8 +22,9 @@
 //     block is not bounded by LDS: every CU gets ONE contiguous range of the launch (persistent blocks:
 //     one prologue per CU, 63 rows of halo per CU).
 //
-// A slot is 2048*KS bytes >= 31 rows + one K-padded row (KS = ceil(2D/32) k steps), so an issuing wave
-// issues exactly KS DMAs per round.  Needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
+// A contiguous slot is 2048*KS bytes >= 31 rows + one K-padded row (KS = ceil(2D/32) k steps), so an issuing wave
+// issues exactly KS DMAs per round; it needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
+// Every other decimation (odd D, D > 256 in several k-step ranges) uses row-staged slots, see RingGeo.
 #include "mfma_common.h"
 
 #include <cmath>
@@ -51,12 +52,27 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void *)p));
 }
 
-// rounds of two tiles the ring holds: as many as fit beside the 4.5 KiB window, at most 5 (vmcnt literals below)
-__host__ __device__ constexpr int ring_rounds(int ks)
-{
-    const int fit = (160 * 1024 - RG_ACC_BYTES) / (2 * 2048 * ks);
-    return fit > 5 ? 5 : (fit < 2 ? 2 : fit);
-}
+// Two ways a tile (32 data rows) sits in a ring slot:
+//   contiguous (ROWS = false): the 32*D frames exactly as they lie in the capture, 2*KS chunks of 1 KiB -- needs
+//     16-byte aligned rows (D % 4 == 0) and all k steps of a row in one pass (KS <= 16);
+//   row-staged (ROWS = true): row j's k-step range of THIS pass, 64*KS bytes, at a pitch of 64*KS + 16 bytes (16 bytes
+//     of padding: rows 4 banks apart, conflict-free reads), one DMA per row with 4*KS active lanes.  Any D, and the
+//     k-step ranges of a long row (D = 521: 33 k steps in three passes of 11) each fetch only their own third of every
+//     row, so three passes read the capture about once instead of three times.  Always with loader waves.
+template <int KS, bool ROWS>
+struct RingGeo {
+    static constexpr int PITCH = 64 * KS + 16;
+    static constexpr int SLOT = ROWS ? 32 * PITCH : 2048 * KS;
+    static constexpr bool LOADERS = ROWS || KS <= 8;  // two extra waves feed the ring and emit (needs <= 168 registers)
+    static constexpr int NDMA = ROWS ? 32 : (LOADERS ? 2 * KS : KS);  // DMAs per issuing wave and round
+    static constexpr int FIT = (160 * 1024 - RG_ACC_BYTES) / (2 * SLOT);
+    static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
+    static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
+    static constexpr int R = R0 > 5 ? 5 : (R0 < 2 ? 2 : R0);  // rounds of two tiles the ring holds
+    static constexpr int THREADS = (RG_WAVES + (LOADERS ? 2 : 0)) * kWave;
+    static_assert(R * 2 * SLOT + RG_ACC_BYTES <= 160 * 1024, "ring + window exceed LDS");
+    static_assert((R - 2) * NDMA <= 63, "vmcnt is a 6-bit counter");
+};
 
 struct RingCtx {
     char *smem;
@@ -138,42 +154,44 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
     e.wc = nc;
 }
 
-// LOADERS: the block has two extra waves (one per column parity) that do nothing but feed the ring and emit
-// finished outputs, and the eight multiplying waves never touch a DMA.  Used when the kernel fits 168 registers
-// (three waves on two of the SIMDs); otherwise (long rows) two multiplying waves per parity issue the DMAs and
-// wave RG_EMIT_WAVE emits.
-__host__ __device__ constexpr bool ring_has_loaders(int ks) { return ks <= 8; }
-
-template <int KS>
-__device__ __forceinline__ void ring_wait_and_barrier(int younger, int per_round)
+template <int KS, bool ROWS>
+__device__ __forceinline__ void ring_wait_and_barrier(int younger)
 {
     // an issuing wave's DMAs of round r have landed once only those of the younger rounds are outstanding
-    constexpr int R = ring_rounds(KS);
-    (void)per_round;
-    constexpr int N = ring_has_loaders(KS) ? 2 * KS : KS;  // DMAs per issuing wave and round
-    if (R >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * N) : "memory");
-    else if (R >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * N) : "memory");
-    else if (R >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+    using G = RingGeo<KS, ROWS>;
+    constexpr int R = G::R, N = G::NDMA;
+    if (R >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 5 ? 3 * N : 0) : "memory");
+    else if (R >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 4 ? 2 * N : 0) : "memory");
+    else if (R >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 3 ? N : 0) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    static_assert(3 * N <= 63 || R < 5, "vmcnt is a 6-bit counter");
 }
 
 // A loader wave (parity cp): per round, wait for its DMAs of this round, join the barrier, refill the slot the
 // previous round has left with the tile R-1 rounds ahead (all 2*KS chunks), and emit the group of 64 outputs that
 // became complete two rounds ago when that group's parity is its own.
-template <int KS, int DBG, bool ACC64>
+template <int KS, int DBG, bool ACC64, bool ROWS>
 __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 {
-    constexpr int R = ring_rounds(KS);
-    constexpr int SLOT = 2048 * KS;
+    using G = RingGeo<KS, ROWS>;
+    constexpr int R = G::R, SLOT = G::SLOT;
     constexpr bool STREAM = !(DBG & 16);
     const int cp = c.cp;
     auto issue_tile = [&](int tile, int slot) {
         const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
         char *dst = c.smem + (slot * 2 + cp) * SLOT;
+        if constexpr (ROWS) {
+            // one DMA per data row: lanes 0 .. 4*KS-1 fetch the 64*KS bytes of this pass's k steps
+            const long long row_bytes = c.tile_bytes >> 5;
+            if (c.lane < 4 * KS) {
 #pragma unroll
-        for (int i = 0; i < 2 * KS; ++i)
-            __builtin_amdgcn_global_load_lds(src + i * 1024, (ring_lds_t *)(dst + i * 1024), 16, 0, 0);
+                for (int j = 0; j < 32; ++j)
+                    __builtin_amdgcn_global_load_lds(src + j * row_bytes, (ring_lds_t *)(dst + j * G::PITCH), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2 * KS; ++i)
+                __builtin_amdgcn_global_load_lds(src + i * 1024, (ring_lds_t *)(dst + i * 1024), 16, 0, 0);
+        }
     };
     if (STREAM) {
 #pragma unroll
@@ -191,7 +209,7 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
     a2.rot64_im = st_im;
     int slot = 0;
     for (int r = 0; r < c.rounds; ++r) {
-        if (STREAM) ring_wait_and_barrier<KS>(min(R - 2, c.rounds - 1 - r), 0);
+        if (STREAM) ring_wait_and_barrier<KS, ROWS>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
         if (STREAM && r + R - 1 < c.rounds) issue_tile(2 * (r + R - 1) + cp, (slot == 0) ? R - 1 : slot - 1);
         if (r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) {
@@ -215,11 +233,12 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ACC64, bool ISSUER, bool EMIT, bool DEFER>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool ISSUER, bool EMIT, bool DEFER>
 __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
 {
-    constexpr int R = ring_rounds(KS);
-    constexpr int SLOT = 2048 * KS;
+    using G = RingGeo<KS, ROWS>;
+    constexpr int R = G::R, SLOT = G::SLOT;
+    static_assert(!(ROWS && ISSUER), "row-staged slots are always fed by loader waves");
     constexpr bool STREAM = ISSUER && !(DBG & 16);
     const int rt = c.rt, cp = c.cp;
     auto issue = [&](int tile, int slot, int i) {
@@ -273,7 +292,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     int held_t = -1;
     int slot = 0;
     for (int r = 0; r < c.rounds; ++r) {
-        if (STREAM) ring_wait_and_barrier<KS>(min(R - 2, c.rounds - 1 - r), 0);
+        if (STREAM) ring_wait_and_barrier<KS, ROWS>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
         if (EMIT && r >= RG_EMIT_LAG) {
             asm volatile("" ::: "memory");
@@ -357,18 +376,14 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     }
 }
 
-template <int KS>
-constexpr int ring_threads() { return (RG_WAVES + (ring_has_loaders(KS) ? 2 : 0)) * kWave; }
-
 // One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
 // stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
-template <int KS, int DBG, bool ACC64>
+template <int KS, int DBG, bool ACC64, bool ROWS>
 __device__ __forceinline__ void ring_block(const MfmaArgs &a)
 {
-    constexpr int R = ring_rounds(KS);
-    constexpr int SLOT = 2048 * KS;
-    constexpr bool LOADERS = ring_has_loaders(KS);
-    static_assert(R * 2 * SLOT + RG_ACC_BYTES <= 160 * 1024, "ring + window exceed LDS");
+    using G = RingGeo<KS, ROWS>;
+    constexpr int R = G::R, SLOT = G::SLOT;
+    constexpr bool LOADERS = G::LOADERS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -386,20 +401,20 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a)
     c.rounds = (c.tiles + 1) >> 1;
     c.smem = smem;
     c.s_acc = reinterpret_cast<int *>(smem + R * 2 * SLOT);
-    for (int i = tid; i < RG_ACC_BYTES / 4; i += ring_threads<KS>()) c.s_acc[i] = 0;
+    for (int i = tid; i < RG_ACC_BYTES / 4; i += G::THREADS) c.s_acc[i] = 0;
 
     // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
     const long long row_bytes = 4LL * a.D;
     c.tile_bytes = 32 * row_bytes;
     const char *stream = reinterpret_cast<const char *>(a.raw) + 4 * ((c.m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
-                         c.lane * 16;
-    c.lane_off = c.col * static_cast<int>(row_bytes) + 32 * c.h;
+                         c.lane * 16 + (ROWS ? 64 * a.k_first : 0);
+    c.lane_off = c.col * (ROWS ? G::PITCH : static_cast<int>(row_bytes)) + 32 * c.h;
 
     if (LOADERS && wave >= RG_WAVES) {
         c.cp = wave - RG_WAVES;
         c.stream0 = stream;
         __syncthreads();
-        ring_loader<KS, DBG, ACC64>(a, c);
+        ring_loader<KS, DBG, ACC64, ROWS>(a, c);
         return;
     }
     // tap fragments of this wave's row tile: registers for the whole block
@@ -416,17 +431,81 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a)
     }
     __syncthreads();
     c.stream0 = stream + (c.rt & 1) * 1024;
-    if (LOADERS) {
-        if (c.cp) ring_main<KS, DBG, ACC64, false, false, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, false, false, false>(a, c, fq);
+    if constexpr (LOADERS) {
+        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, false, false, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, ROWS, false, false, false>(a, c, fq);
+    } else {
+        // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
+        if ((c.rt >> 1) == c.cp) {
+            if (c.cp) ring_main<KS, DBG, ACC64, ROWS, true, false, true>(a, c, fq);
+            else ring_main<KS, DBG, ACC64, ROWS, true, false, false>(a, c, fq);
+        } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, ROWS, false, true, false>(a, c, fq);
+        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, false, false, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, ROWS, false, false, false>(a, c, fq);
     }
-    // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
-    else if ((c.rt >> 1) == c.cp) {
-        if (c.cp) ring_main<KS, DBG, ACC64, true, false, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, true, false, false>(a, c, fq);
-    } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, false, true, false>(a, c, fq);
-    else if (c.cp) ring_main<KS, DBG, ACC64, false, false, true>(a, c, fq);
-    else ring_main<KS, DBG, ACC64, false, false, false>(a, c, fq);
+}
+
+template <int KS, int DBG, bool ACC64>
+__global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring(MfmaArgs a)
+{
+    ring_block<KS, DBG, ACC64, false>(a);
+}
+
+// The same block under its own name for short launches (the mixer-sign probes: a few thousand outputs in blocks of
+// 64), so that profiles keep the capture-long launches and the probes in separate rows.
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_short(MfmaArgs a)
+{
+    ring_block<KS, 0, false, false>(a);
+}
+
+// Row-staged slots (any D, one k-step range per pass), int32 sums.
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, true>::THREADS), 3) void k_channelize_mfma_s16_ring_rows(MfmaArgs a)
+{
+    ring_block<KS, 0, false, true>(a);
+}
+
+template <typename K>
+static void ring_launch_kernel(K kernel, int threads, const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool &attr_set)
+{
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, a);
+}
+
+template <int KS, int DBG, bool ACC64>
+static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    static bool attr_set = false;
+    ring_launch_kernel(k_channelize_mfma_s16_ring<KS, DBG, ACC64>, RingGeo<KS, false>::THREADS, a, blocks, lds, stream, attr_set);
+}
+
+template <int KS>
+static void ring_launch_short(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    static bool attr_set = false;
+    ring_launch_kernel(k_channelize_mfma_s16_ring_short<KS>, RingGeo<KS, false>::THREADS, a, blocks, lds, stream, attr_set);
+}
+
+template <int KS>
+static void ring_launch_rows(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    static bool attr_set = false;
+    ring_launch_kernel(k_channelize_mfma_s16_ring_rows<KS>, RingGeo<KS, true>::THREADS, a, blocks, lds, stream, attr_set);
+}
+
+constexpr int RG_ROWS_MAX_KS = 11;  // 8*KS tap registers + the rest must stay within 168 (three waves on two SIMDs)
+
+// 0: the ring kernels do not apply; 1: contiguous slots; 2: row-staged slots (int32 sums only)
+int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64)
+{
+    const int ks_all = (2 * decimation + 31) / 32;
+    if (decimation >= 4 && (decimation & 3) == 0 && ks_all <= RG_MAX_KS && k_first == 0 && k_count == ks_all) return 1;
+    if (!acc64 && decimation >= 1 && k_count >= 1 && k_count <= RG_ROWS_MAX_KS && k_first >= 0 && k_first + k_count <= ks_all) return 2;
+    return 0;
 }
 
 bool mfma_ring_supported(int decimation)
@@ -435,58 +514,36 @@ bool mfma_ring_supported(int decimation)
     return decimation >= 4 && (decimation & 3) == 0 && ks <= RG_MAX_KS;
 }
 
-size_t mfma_ring_lds_bytes(int ksteps) { return static_cast<size_t>(ring_rounds(ksteps)) * 2 * 2048 * ksteps + RG_ACC_BYTES; }
-
-template <int KS, int DBG, bool ACC64>
-__global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) void k_channelize_mfma_s16_ring(MfmaArgs a)
-{
-    ring_block<KS, DBG, ACC64>(a);
-}
-
-// The same block under its own name for short launches (the mixer-sign probes: a few thousand outputs in blocks of
-// 64), so that profiles keep the capture-long launches and the probes in separate rows.
 template <int KS>
-__global__ __launch_bounds__(ring_threads<KS>(), ring_has_loaders(KS) ? 3 : 2) void k_channelize_mfma_s16_ring_short(MfmaArgs a)
+static constexpr size_t ring_bytes_of(bool rows)
 {
-    ring_block<KS, 0, false>(a);
+    return rows ? static_cast<size_t>(RingGeo<KS, true>::R) * 2 * RingGeo<KS, true>::SLOT + RG_ACC_BYTES
+                : static_cast<size_t>(RingGeo<KS, false>::R) * 2 * RingGeo<KS, false>::SLOT + RG_ACC_BYTES;
 }
 
-template <int KS, int DBG, bool ACC64>
-static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+size_t mfma_ring_lds_bytes(int ksteps, bool rows)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_ring<KS, DBG, ACC64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    switch (ksteps) {
+#define RG_B(K) case K: return (rows && K > RG_ROWS_MAX_KS) ? 0 : ring_bytes_of<(K <= 16 ? K : 16)>(rows)
+        RG_B(1); RG_B(2); RG_B(3); RG_B(4); RG_B(5); RG_B(6); RG_B(7); RG_B(8);
+        RG_B(9); RG_B(10); RG_B(11); RG_B(12); RG_B(13); RG_B(14); RG_B(15); RG_B(16);
+#undef RG_B
+        default: return 0;
     }
-    hipLaunchKernelGGL((k_channelize_mfma_s16_ring<KS, DBG, ACC64>), dim3(blocks), dim3(ring_threads<KS>()), lds, stream, a);
-}
-
-template <int KS>
-static void ring_launch_short(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
-{
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16_ring_short<KS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_channelize_mfma_s16_ring_short<KS>), dim3(blocks), dim3(ring_threads<KS>()), lds, stream, a);
 }
 
 // debug bit 7 (128) selects the 32-bit sums (needs fragments from dsp_plan.plan_mfma(acc32=True))
-void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows)
 {
     const int dbg = a.debug & (1 | 16 | 32);
     const bool acc64 = !(a.debug & 128);
-    if (!dbg && !acc64 && a.range < 512) {  // short launch (int32 sums): same code, its own kernel name
+    if (rows) {
         switch (a.ksteps) {
-#define RG_SHORT(K) case K: return ring_launch_short<K>(a, blocks, lds, stream)
-            RG_SHORT(1); RG_SHORT(2); RG_SHORT(3); RG_SHORT(4); RG_SHORT(5); RG_SHORT(6); RG_SHORT(7); RG_SHORT(8);
-            RG_SHORT(9); RG_SHORT(10); RG_SHORT(11); RG_SHORT(12); RG_SHORT(13); RG_SHORT(14); RG_SHORT(15); RG_SHORT(16);
-#undef RG_SHORT
-            default: break;
+#define RG_ROWS(K) case K: return ring_launch_rows<K>(a, blocks, lds, stream)
+            RG_ROWS(1); RG_ROWS(2); RG_ROWS(3); RG_ROWS(4); RG_ROWS(5); RG_ROWS(6); RG_ROWS(7); RG_ROWS(8);
+            RG_ROWS(9); RG_ROWS(10); RG_ROWS(11);
+#undef RG_ROWS
+            default: return;
         }
     }
     if (dbg && a.ksteps == 7 && !acc64) {  // diagnostic instantiations exist for the benchmark shape only
@@ -496,6 +553,15 @@ void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_
             case 17: return ring_launch_one<7, 17, false>(a, blocks, lds, stream);
             case 32: return ring_launch_one<7, 32, false>(a, blocks, lds, stream);
             case 33: return ring_launch_one<7, 33, false>(a, blocks, lds, stream);
+            default: break;
+        }
+    }
+    if (!dbg && !acc64 && a.range < 512) {  // short launch (int32 sums): same code, its own kernel name
+        switch (a.ksteps) {
+#define RG_SHORT(K) case K: return ring_launch_short<K>(a, blocks, lds, stream)
+            RG_SHORT(1); RG_SHORT(2); RG_SHORT(3); RG_SHORT(4); RG_SHORT(5); RG_SHORT(6); RG_SHORT(7); RG_SHORT(8);
+            RG_SHORT(9); RG_SHORT(10); RG_SHORT(11); RG_SHORT(12); RG_SHORT(13); RG_SHORT(14); RG_SHORT(15); RG_SHORT(16);
+#undef RG_SHORT
             default: break;
         }
     }

@@ -235,7 +235,7 @@ def _mfma_layout(ntaps: int, decimation: int, group: int):
     return ksteps, kc, ok, flat
 
 
-def plan_mfma(plan: ChannelPlan, acc32: bool = False) -> MfmaPlan:
+def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = None) -> MfmaPlan:
     """Quantise the (already NCO-rotated, scaled) taps to 16-bit fixed point and lay them out as
     the A operand of v_mfma_i32_32x32x32_i8.
 
@@ -260,7 +260,7 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False) -> MfmaPlan:
     n_groups = max(1, -(-(-(-plan.ntaps // D)) // MFMA_Q))
     groups, passes = [], []
     ksteps = -(-2 * D // 32)
-    n_chunks = -(-ksteps // MFMA_MAX_KSTEPS_PER_PASS)
+    n_chunks = -(-ksteps // (max_ksteps or MFMA_MAX_KSTEPS_PER_PASS))  # k-step ranges: one pass each
     bounds = [round(i * ksteps / n_chunks) for i in range(n_chunks + 1)]
     for gi in range(n_groups):
         _, kc, ok, flat = _mfma_layout(plan.ntaps, D, gi)

@@ -159,6 +159,7 @@ class _ChannelKernel:
     #: (S1 << 32) + S2 with 16-bit taps -- the same integers as the per-lane kernel (~1e-6) -- at +10 % kernel time
     #: (ds_add_u64 moves 3 dwords and takes two passes through the LDS banks).  Both are exact integer sums.
     ring_acc32 = True
+    RING_ROWS_KSTEPS = 11  # k steps per pass of the row-staged ring kernel (its tap fragments live in registers)
     _VARIANT = {"plain": (0, 0), "ring": (64, 0)}  # flags, extra LDS bytes
     mfma_min_outputs = 32768
 
@@ -177,6 +178,15 @@ class _ChannelKernel:
         self._lock = threading.RLock()  # kernels are shared through _KERNEL_CACHE; a launch mutates the pass parameters
         self.last_kernel = "k_channelize_v1"
         self._ring_bytes = int(N.lib().iqa_mfma_ring_bytes(plan.decimation)) if plan.fmt == "s16" else 0
+        # which ring kernel covers this decimation: 1 = contiguous slots (all k steps in one pass), 2 = row-staged slots
+        # (any D, k-step ranges of <= RING_ROWS_KSTEPS, int32 sums only), 0 = none -> the per-lane kernel
+        ks_all = -(-2 * plan.decimation // 32)
+        self._ring_mode = 0
+        if plan.fmt == "s16" and self.mfma_variant == "ring":
+            acc32 = int(bool(self.ring_acc32))
+            self._ring_mode = int(N.lib().iqa_mfma_ring_mode(plan.decimation, 0, ks_all, acc32))
+            if self._ring_mode == 0:
+                self._ring_mode = int(N.lib().iqa_mfma_ring_mode(plan.decimation, 0, min(ks_all, self.RING_ROWS_KSTEPS), acc32))
         self._mfma_ok = bool(self.use_mfma and P.mfma_supported(plan))
 
     def _ensure_mfma(self):
@@ -185,8 +195,9 @@ class _ChannelKernel:
 
     def _ensure_mfma_locked(self):
         if self.mfma is None:
-            ring = self.mfma_variant == "ring" and bool(self._ring_bytes) and -(-2 * self.plan.decimation // 32) <= P.MFMA_MAX_KSTEPS_PER_PASS
-            mp = P.plan_mfma(self.plan, acc32=ring and self.ring_acc32)
+            ring = self.mfma_variant == "ring" and self._ring_mode != 0
+            mp = P.plan_mfma(self.plan, acc32=ring and self.ring_acc32,
+                             max_ksteps=self.RING_ROWS_KSTEPS if self._ring_mode == 2 else None)
             self.mfma = mp
             self.afrag_dev = [D.from_numpy(g.afrag.reshape(-1).view(np.uint8)) for g in mp.groups]
             self.mfma_params = []
@@ -241,8 +252,8 @@ class _ChannelKernel:
         ksteps = -(-2 * d // 32)
         n_groups = max(1, -(-(-(-self.plan.ntaps // d)) // P.MFMA_Q))
         m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, d, ksteps, n_groups)
-        if self.mfma_variant == "ring" and self._ring_bytes:
-            # a ring tile is fetched as 2048*ksteps contiguous bytes from its first frame
+        if self.mfma_variant == "ring" and self._ring_mode == 1:
+            # a contiguous ring tile is fetched as 2048*ksteps bytes from its first frame
             m_b = min(m_b, (n_frames + consumed - 512 * ksteps - 1) // d + 2)
         return (m_a, m_b) if m_b > m_a else (m_first, m_first)
 
@@ -269,7 +280,7 @@ class _ChannelKernel:
         filter's transient and read a snippet of a longer buffer).  False (nothing launched) when the range is not
         wholly interior or the capture format has no matrix-core kernel."""
         with self._lock:
-            if not (self._mfma_ok and self.mfma_variant == "ring" and self._ring_bytes) or n_out < 64:
+            if not (self._mfma_ok and self.mfma_variant == "ring" and self._ring_mode) or n_out < 64:
                 return False
             m_a, m_b = self._interior(0, n_frames, m_first, n_out)
             if m_a != m_first or m_b != m_first + n_out:

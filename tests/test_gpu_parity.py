@@ -587,8 +587,9 @@ def test_mfma_channelizer_vs_valu_and_oracle(A, fs, d, bw, n, variant):
     """The matrix-core path (exact int32 accumulation of int8 pieces, fixed-point taps) against the float32 VALU
     kernel and the oracle: error is the documented tap-quantisation floor (16-bit taps, ~2e-6 of full scale, for
     the per-lane kernel; ~14-bit taps, ~1e-5, for the ring kernel, which keeps 256*S1+S2 in one int32), results
-    are bit-reproducible, and head/tail outputs (history / end of block) are seamless.  Where the ring kernel
-    does not apply (D % 4 != 0, D > 256) the variant falls back to the per-lane kernel."""
+    are bit-reproducible, and head/tail outputs (history / end of block) are seamless.  The ring kernel covers every
+    shape: contiguous slots where rows are 16-byte aligned and fit one pass, row-staged slots for C1 (D = 26) and C5
+    (D = 521: three k-step ranges of 11, chained through partial sums, each fetching its own third of every row)."""
     import torch
 
     from iq_to_audio_amd import _dev as D
@@ -619,8 +620,10 @@ def test_mfma_channelizer_vs_valu_and_oracle(A, fs, d, bw, n, variant):
         PR._ChannelKernel.use_mfma = True
         PR._ChannelKernel.mfma_min_outputs, PR._ChannelKernel.mfma_variant = old_min, old_variant
     is_ring = ch._kernel.last_kernel.endswith("_ring")
-    assert is_ring == (variant == "ring" and d % 4 == 0 and d <= 256)
-    tol_rms, tol_max = (2e-5, 1e-4) if is_ring else (4e-6, 2e-5)
+    assert is_ring == (variant == "ring")  # contiguous slots for D % 4 == 0, D <= 256; row-staged slots for C1 / C5
+    # int32 sums: the tap unit is ~ sum|g| * sqrt(2) / 2^24 for every filter, so the error grows with sqrt(L)
+    grow = max(1.0, float(np.sqrt(len(taps) / 6401.0)))
+    tol_rms, tol_max = (1.4e-5 * grow, 1e-4 * grow) if is_ring else (4e-6, 2e-5)
     valu, mfma = outs[False].cpu().numpy(), outs[True].cpu().numpy()
     assert valu.shape == mfma.shape == (-(-n // d),)
     n_cpu = 1_000_000
