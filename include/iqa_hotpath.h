@@ -126,10 +126,10 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
 typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
     int32_t reserved;          /* data-path variant + diagnostics flags.  0 = per-lane row loads; 64 = block-wide
-                                * contiguous LDS-DMA ring (needs iqa_mfma_ring_bytes(D) > 0 and a single k-step
-                                * range; LDS = iqa_mfma_ring_bytes(D) whatever outputs_per_block is); 64|128 = the same with
-                                * 256*S1 + S2 kept in one int32, for fragments from a quantisation that bounds that sum:
-                                * dsp_plan.plan_mfma(acc32=True);
+                                * LDS-DMA ring, 64-bit sums (needs iqa_mfma_ring_mode(D, k_first, k_count, 0) != 0;
+                                * its LDS does not depend on outputs_per_block); 64|128 = the ring with 256*S1 + S2
+                                * in one int32, for fragments from a quantisation that bounds that sum
+                                * (dsp_plan.plan_mfma(acc32=True); iqa_mfma_ring_mode(..., 1) != 0);
                                 * bits 0,1,4,5 are timing diagnostics, never set in production */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
