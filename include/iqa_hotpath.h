@@ -106,7 +106,7 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
                    void *stream);
 
 /*
- * int8-MFMA form of iqa_channelize for int16 captures (same reference lines, same result up to the
+ * int8-MFMA form of iqa_channelize for int16 captures -- and, ring variant only, uint8 ones -- (same reference lines, same result up to the
  * 16-bit fixed-point tap quantisation, ~1e-6 of full scale): the decimating FIR is evaluated as a
  * dense integer GEMM on the matrix cores with exact int32 accumulation (see channelize_mfma.hip).
  * It covers only outputs whose whole read range lies inside raw_dev[0, n_frames): columns
@@ -148,11 +148,13 @@ int64_t iqa_mfma_afrag_bytes(int32_t decimation);
  * contiguous bytes, so the last output of a ring pass must satisfy
  * (m_last - 1)*D + 512*ceil(2D/32) < consumed + n_frames. */
 int64_t iqa_mfma_ring_bytes(int32_t decimation);
-/* Which ring kernel covers a pass over k steps [k_first, k_first + k_count) at this decimation: 0 = none (use the
- * per-lane kernel, reserved = 0), 1 = contiguous slots (all k steps in one pass, D % 4 == 0, D <= 256), 2 = row-staged
- * slots (any D, k_count <= 11, int32 sums only: acc32 != 0).  Mode 2 reads exactly the frames the per-lane kernel
- * reads; mode 1 needs the slack described above. */
-int32_t iqa_mfma_ring_mode(int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32);
+/* Which ring kernel covers a pass over k steps [k_first, k_first + k_count) at this decimation: 0 = none (int16: use
+ * the per-lane kernel, reserved = 0; uint8: use iqa_channelize), 1 = contiguous slots (int16, all k steps in one
+ * pass, D % 4 == 0, D <= 256), 2 = row-staged slots (int16 or uint8, any D, k_count <= 11, int32 sums only:
+ * acc32 != 0).  Mode 2 reads exactly the frames the per-lane kernel reads; mode 1 needs the slack described above.
+ * For uint8 captures (fmt = IQA_FMT_U8, reserved = 64|128) the data have a single byte piece: pass
+ * unit = tap LSB / 256 and c_re = c_im = 0 (dsp_plan.plan_mfma does). */
+int32_t iqa_mfma_ring_mode(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32);
 int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,
                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first, int64_t n_out,
                         void *z_out_dev, void *stream);

@@ -209,13 +209,13 @@ extern "C" int64_t iqa_mfma_ring_bytes(int32_t decimation)
 {
     // LDS bytes of a ring-kernel block with contiguous slots for this decimation, or 0 when that form does not apply
     if (decimation < 1 || !mfma_ring_supported(decimation)) return 0;
-    return static_cast<int64_t>(mfma_ring_lds_bytes((2 * decimation + 31) / 32, false));
+    return static_cast<int64_t>(mfma_ring_lds_bytes((2 * decimation + 31) / 32, false, false));
 }
 
-extern "C" int32_t iqa_mfma_ring_mode(int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32)
+extern "C" int32_t iqa_mfma_ring_mode(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32)
 {
-    if (decimation < 1) return 0;
-    return mfma_ring_mode(decimation, k_first, k_count, acc32 == 0);
+    if (decimation < 1 || (fmt != IQA_FMT_S16 && fmt != IQA_FMT_U8)) return 0;
+    return mfma_ring_mode(decimation, k_first, k_count, acc32 == 0, fmt == IQA_FMT_U8);
 }
 
 extern "C" int64_t iqa_mfma_afrag_bytes(int32_t decimation)
@@ -231,7 +231,9 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
                                    int64_t n_out, void *z_out_dev, void *stream)
 {
     if (p == nullptr || q == nullptr) return fail_inval("params is NULL");
-    if (p->fmt != IQA_FMT_S16) return fail_inval("the MFMA channelizer takes int16 captures only");
+    const bool u8 = p->fmt == IQA_FMT_U8;  // uint8 captures: row-staged ring kernel only (reserved = 64|128)
+    if (p->fmt != IQA_FMT_S16 && !(u8 && (q->reserved & 64)))
+        return fail_inval("the MFMA channelizer takes int16 captures (and uint8 ones with the ring variant) only");
     if (p->ntaps <= 0 || p->decimation < 1) return fail_inval("bad ntaps/decimation");
     const int64_t D = p->decimation;
     // consumed may be negative: raw_dev then starts |consumed| frames BEFORE global frame 0 (a lead-in of zeros --
@@ -268,7 +270,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
     size_t lds = static_cast<size_t>(ksteps) * MF_KSTEP_BYTES + 4 * acc_len * sizeof(int);
     int ring_mode = 0;
     if (ring) {
-        ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, !(q->reserved & 128));
+        ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, !(q->reserved & 128), u8);
         if (ring_mode == 0)
             return fail_inval("the ring kernel does not cover this (decimation, k-step range, sum width): see iqa_mfma_ring_mode");
         if (ring_mode == 1) {
@@ -279,7 +281,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
             if (t_last * D + 1 - consumed + slot_frames > n_frames || t_full * D + 1 - consumed + slot_frames > n_frames)
                 return fail_inval("ring kernel range reads outside the block (use iqa_channelize for the edges)");
         }  // row-staged slots read exactly what the per-lane kernel reads: covered by the checks above
-        lds = mfma_ring_lds_bytes(ksteps, ring_mode == 2);  // ring + sliding window: independent of outputs_per_block
+        lds = mfma_ring_lds_bytes(ksteps, ring_mode == 2, u8);  // ring + sliding window: independent of outputs_per_block
     }
     if (lds > 160 * 1024) return fail_inval("tap fragments + accumulators exceed 160 KiB of LDS");
 
@@ -317,7 +319,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
     if (ring) {
-        mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2);
+        mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2, u8);
         return check_launch("k_channelize_mfma_s16_ring");
     }
     static bool attr_set = false;

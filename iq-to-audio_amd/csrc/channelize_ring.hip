@@ -59,9 +59,13 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 //     of padding: rows 4 banks apart, conflict-free reads), one DMA per row with 4*KS active lanes.  Any D, and the
 //     k-step ranges of a long row (D = 521: 33 k steps in three passes of 11) each fetch only their own third of every
 //     row, so three passes read the capture about once instead of three times.  Always with loader waves.
-template <int KS, bool ROWS>
+// U8 (row-staged only): uint8 I/Q captures -- a k step is 32 bytes of a row, one 16-byte fragment per lane, the
+// offset-binary bytes become int8 with one XOR, and there is a single data piece: two MFMAs per k step (q1*v, q2*v).
+template <int KS, bool ROWS, bool U8 = false>
 struct RingGeo {
-    static constexpr int PITCH = 64 * KS + 16;
+    static_assert(ROWS || !U8, "uint8 captures use row-staged slots");
+    static constexpr int KBYTES = U8 ? 32 : 64;  // bytes of a row per k step
+    static constexpr int PITCH = KBYTES * KS + 16;
     static constexpr int SLOT = ROWS ? 32 * PITCH : 2048 * KS;
     static constexpr bool LOADERS = ROWS || KS <= 8;  // two extra waves feed the ring and emit (needs <= 168 registers)
     static constexpr int NDMA = ROWS ? 32 : (LOADERS ? 2 * KS : KS);  // DMAs per issuing wave and round
@@ -154,11 +158,11 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
     e.wc = nc;
 }
 
-template <int KS, bool ROWS>
+template <int KS, bool ROWS, bool U8>
 __device__ __forceinline__ void ring_wait_and_barrier(int younger)
 {
     // an issuing wave's DMAs of round r have landed once only those of the younger rounds are outstanding
-    using G = RingGeo<KS, ROWS>;
+    using G = RingGeo<KS, ROWS, U8>;
     constexpr int R = G::R, N = G::NDMA;
     if (R >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 5 ? 3 * N : 0) : "memory");
     else if (R >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 4 ? 2 * N : 0) : "memory");
@@ -169,10 +173,10 @@ __device__ __forceinline__ void ring_wait_and_barrier(int younger)
 // A loader wave (parity cp): per round, wait for its DMAs of this round, join the barrier, refill the slot the
 // previous round has left with the tile R-1 rounds ahead (all 2*KS chunks), and emit the group of 64 outputs that
 // became complete two rounds ago when that group's parity is its own.
-template <int KS, int DBG, bool ACC64, bool ROWS>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8>
 __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 {
-    using G = RingGeo<KS, ROWS>;
+    using G = RingGeo<KS, ROWS, U8>;
     constexpr int R = G::R, SLOT = G::SLOT;
     constexpr bool STREAM = !(DBG & 16);
     const int cp = c.cp;
@@ -180,9 +184,9 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
         const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
         char *dst = c.smem + (slot * 2 + cp) * SLOT;
         if constexpr (ROWS) {
-            // one DMA per data row: lanes 0 .. 4*KS-1 fetch the 64*KS bytes of this pass's k steps
+            // one DMA per data row: the first KBYTES*KS/16 lanes fetch the bytes of this pass's k steps
             const long long row_bytes = c.tile_bytes >> 5;
-            if (c.lane < 4 * KS) {
+            if (c.lane < (G::KBYTES / 16) * KS) {
 #pragma unroll
                 for (int j = 0; j < 32; ++j)
                     __builtin_amdgcn_global_load_lds(src + j * row_bytes, (ring_lds_t *)(dst + j * G::PITCH), 16, 0, 0);
@@ -209,7 +213,7 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
     a2.rot64_im = st_im;
     int slot = 0;
     for (int r = 0; r < c.rounds; ++r) {
-        if (STREAM) ring_wait_and_barrier<KS, ROWS>(min(R - 2, c.rounds - 1 - r));
+        if (STREAM) ring_wait_and_barrier<KS, ROWS, U8>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
         if (STREAM && r + R - 1 < c.rounds) issue_tile(2 * (r + R - 1) + cp, (slot == 0) ? R - 1 : slot - 1);
         if (r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) {
@@ -233,10 +237,10 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ACC64, bool ROWS, bool ISSUER, bool EMIT, bool DEFER>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER>
 __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
 {
-    using G = RingGeo<KS, ROWS>;
+    using G = RingGeo<KS, ROWS, U8>;
     constexpr int R = G::R, SLOT = G::SLOT;
     static_assert(!(ROWS && ISSUER), "row-staged slots are always fed by loader waves");
     constexpr bool STREAM = ISSUER && !(DBG & 16);
@@ -292,7 +296,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     int held_t = -1;
     int slot = 0;
     for (int r = 0; r < c.rounds; ++r) {
-        if (STREAM) ring_wait_and_barrier<KS, ROWS>(min(R - 2, c.rounds - 1 - r));
+        if (STREAM) ring_wait_and_barrier<KS, ROWS, U8>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
         if (EMIT && r >= RG_EMIT_LAG) {
             asm volatile("" ::: "memory");
@@ -315,13 +319,31 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             auto tile_body = [&](auto pf_c) {
                 constexpr bool PF = decltype(pf_c)::value;
                 constexpr int PD = KS < 2 ? KS : 2;
+                v16i_t acc1, acc2;
+                if constexpr (U8) {
+                    // uint8 frames: this lane's 16 bytes of a k step are 8 frames; u ^ 0x80 = u - 128 as int8
+                    v4i_t du[KS];
+#pragma unroll
+                    for (int ks = 0; ks < PD; ++ks) du[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * ks);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        v4i_t v = du[ks];
+                        v.x ^= 0x80808080;
+                        v.y ^= 0x80808080;
+                        v.z ^= 0x80808080;
+                        v.w ^= 0x80808080;
+                        if (ks + PD < KS) du[ks + PD] = *reinterpret_cast<const v4i_t *>(la + 32 * (ks + PD));
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], v, ks ? acc1 : zero16, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], v, ks ? acc2 : zero16, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
                 v4i_t dd[KS][2];
 #pragma unroll
                 for (int ks = 0; ks < PD; ++ks) {
                     dd[ks][0] = *reinterpret_cast<const v4i_t *>(la + 64 * ks);
                     dd[ks][1] = *reinterpret_cast<const v4i_t *>(la + 64 * ks + 16);
                 }
-                v16i_t acc1, acc2;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
@@ -347,6 +369,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                         acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 if (DBG & 32) acc1 = acc2 = zero16;
                 if (DBG & 1) {
@@ -378,10 +401,10 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 
 // One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
 // stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
-template <int KS, int DBG, bool ACC64, bool ROWS>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8>
 __device__ __forceinline__ void ring_block(const MfmaArgs &a)
 {
-    using G = RingGeo<KS, ROWS>;
+    using G = RingGeo<KS, ROWS, U8>;
     constexpr int R = G::R, SLOT = G::SLOT;
     constexpr bool LOADERS = G::LOADERS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -404,17 +427,18 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a)
     for (int i = tid; i < RG_ACC_BYTES / 4; i += G::THREADS) c.s_acc[i] = 0;
 
     // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
-    const long long row_bytes = 4LL * a.D;
+    constexpr int FB = U8 ? 2 : 4;  // bytes per frame
+    const long long row_bytes = static_cast<long long>(FB) * a.D;
     c.tile_bytes = 32 * row_bytes;
-    const char *stream = reinterpret_cast<const char *>(a.raw) + 4 * ((c.m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
-                         c.lane * 16 + (ROWS ? 64 * a.k_first : 0);
-    c.lane_off = c.col * (ROWS ? G::PITCH : static_cast<int>(row_bytes)) + 32 * c.h;
+    const char *stream = reinterpret_cast<const char *>(a.raw) + FB * ((c.m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
+                         c.lane * 16 + (ROWS ? G::KBYTES * a.k_first : 0);
+    c.lane_off = c.col * (ROWS ? G::PITCH : static_cast<int>(row_bytes)) + (G::KBYTES / 2) * c.h;
 
     if (LOADERS && wave >= RG_WAVES) {
         c.cp = wave - RG_WAVES;
         c.stream0 = stream;
         __syncthreads();
-        ring_loader<KS, DBG, ACC64, ROWS>(a, c);
+        ring_loader<KS, DBG, ACC64, ROWS, U8>(a, c);
         return;
     }
     // tap fragments of this wave's row tile: registers for the whole block
@@ -432,23 +456,23 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a)
     __syncthreads();
     c.stream0 = stream + (c.rt & 1) * 1024;
     if constexpr (LOADERS) {
-        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, false, false, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, ROWS, false, false, false>(a, c, fq);
+        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false>(a, c, fq);
     } else {
         // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
         if ((c.rt >> 1) == c.cp) {
-            if (c.cp) ring_main<KS, DBG, ACC64, ROWS, true, false, true>(a, c, fq);
-            else ring_main<KS, DBG, ACC64, ROWS, true, false, false>(a, c, fq);
-        } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, ROWS, false, true, false>(a, c, fq);
-        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, false, false, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, ROWS, false, false, false>(a, c, fq);
+            if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, true>(a, c, fq);
+            else ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false>(a, c, fq);
+        } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false>(a, c, fq);
+        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false>(a, c, fq);
     }
 }
 
 template <int KS, int DBG, bool ACC64>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring(MfmaArgs a)
 {
-    ring_block<KS, DBG, ACC64, false>(a);
+    ring_block<KS, DBG, ACC64, false, false>(a);
 }
 
 // The same block under its own name for short launches (the mixer-sign probes: a few thousand outputs in blocks of
@@ -456,14 +480,21 @@ __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>:
 template <int KS>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_short(MfmaArgs a)
 {
-    ring_block<KS, 0, false, false>(a);
+    ring_block<KS, 0, false, false, false>(a);
 }
 
 // Row-staged slots (any D, one k-step range per pass), int32 sums.
 template <int KS>
 __global__ __launch_bounds__((RingGeo<KS, true>::THREADS), 3) void k_channelize_mfma_s16_ring_rows(MfmaArgs a)
 {
-    ring_block<KS, 0, false, true>(a);
+    ring_block<KS, 0, false, true, false>(a);
+}
+
+// Row-staged slots, uint8 I/Q captures (cu8 / RTL-SDR), int32 sums.
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, true, true>::THREADS), 3) void k_channelize_mfma_u8_ring_rows(MfmaArgs a)
+{
+    ring_block<KS, 0, false, true, true>(a);
 }
 
 template <typename K>
@@ -497,13 +528,20 @@ static void ring_launch_rows(const MfmaArgs &a, unsigned blocks, size_t lds, hip
     ring_launch_kernel(k_channelize_mfma_s16_ring_rows<KS>, RingGeo<KS, true>::THREADS, a, blocks, lds, stream, attr_set);
 }
 
+template <int KS>
+static void ring_launch_rows_u8(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    static bool attr_set = false;
+    ring_launch_kernel(k_channelize_mfma_u8_ring_rows<KS>, RingGeo<KS, true, true>::THREADS, a, blocks, lds, stream, attr_set);
+}
+
 constexpr int RG_ROWS_MAX_KS = 11;  // 8*KS tap registers + the rest must stay within 168 (three waves on two SIMDs)
 
 // 0: the ring kernels do not apply; 1: contiguous slots; 2: row-staged slots (int32 sums only)
-int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64)
+int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64, bool u8)
 {
     const int ks_all = (2 * decimation + 31) / 32;
-    if (decimation >= 4 && (decimation & 3) == 0 && ks_all <= RG_MAX_KS && k_first == 0 && k_count == ks_all) return 1;
+    if (!u8 && decimation >= 4 && (decimation & 3) == 0 && ks_all <= RG_MAX_KS && k_first == 0 && k_count == ks_all) return 1;
     if (!acc64 && decimation >= 1 && k_count >= 1 && k_count <= RG_ROWS_MAX_KS && k_first >= 0 && k_first + k_count <= ks_all) return 2;
     return 0;
 }
@@ -515,16 +553,17 @@ bool mfma_ring_supported(int decimation)
 }
 
 template <int KS>
-static constexpr size_t ring_bytes_of(bool rows)
+static constexpr size_t ring_bytes_of(bool rows, bool u8)
 {
-    return rows ? static_cast<size_t>(RingGeo<KS, true>::R) * 2 * RingGeo<KS, true>::SLOT + RG_ACC_BYTES
-                : static_cast<size_t>(RingGeo<KS, false>::R) * 2 * RingGeo<KS, false>::SLOT + RG_ACC_BYTES;
+    return u8     ? static_cast<size_t>(RingGeo<KS, true, true>::R) * 2 * RingGeo<KS, true, true>::SLOT + RG_ACC_BYTES
+           : rows ? static_cast<size_t>(RingGeo<KS, true>::R) * 2 * RingGeo<KS, true>::SLOT + RG_ACC_BYTES
+                  : static_cast<size_t>(RingGeo<KS, false>::R) * 2 * RingGeo<KS, false>::SLOT + RG_ACC_BYTES;
 }
 
-size_t mfma_ring_lds_bytes(int ksteps, bool rows)
+size_t mfma_ring_lds_bytes(int ksteps, bool rows, bool u8)
 {
     switch (ksteps) {
-#define RG_B(K) case K: return (rows && K > RG_ROWS_MAX_KS) ? 0 : ring_bytes_of<(K <= 16 ? K : 16)>(rows)
+#define RG_B(K) case K: return (rows && K > RG_ROWS_MAX_KS) ? 0 : ring_bytes_of<(K <= 16 ? K : 16)>(rows, u8)
         RG_B(1); RG_B(2); RG_B(3); RG_B(4); RG_B(5); RG_B(6); RG_B(7); RG_B(8);
         RG_B(9); RG_B(10); RG_B(11); RG_B(12); RG_B(13); RG_B(14); RG_B(15); RG_B(16);
 #undef RG_B
@@ -533,10 +572,19 @@ size_t mfma_ring_lds_bytes(int ksteps, bool rows)
 }
 
 // debug bit 7 (128) selects the 32-bit sums (needs fragments from dsp_plan.plan_mfma(acc32=True))
-void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows)
+void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
 {
     const int dbg = a.debug & (1 | 16 | 32);
     const bool acc64 = !(a.debug & 128);
+    if (u8) {
+        switch (a.ksteps) {
+#define RG_ROWS_U8(K) case K: return ring_launch_rows_u8<K>(a, blocks, lds, stream)
+            RG_ROWS_U8(1); RG_ROWS_U8(2); RG_ROWS_U8(3); RG_ROWS_U8(4); RG_ROWS_U8(5); RG_ROWS_U8(6); RG_ROWS_U8(7); RG_ROWS_U8(8);
+            RG_ROWS_U8(9); RG_ROWS_U8(10); RG_ROWS_U8(11);
+#undef RG_ROWS_U8
+            default: return;
+        }
+    }
     if (rows) {
         switch (a.ksteps) {
 #define RG_ROWS(K) case K: return ring_launch_rows<K>(a, blocks, lds, stream)

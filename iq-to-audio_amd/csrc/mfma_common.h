@@ -75,9 +75,9 @@ __device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, i
 }
 
 // the ring kernels (channelize_ring.hip)
-int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64);  // 0 none, 1 contiguous slots, 2 row-staged slots
+int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64, bool u8);  // 0 none, 1 contiguous, 2 row-staged slots
 bool mfma_ring_supported(int decimation);                                  // mode 1 possible for this decimation
-size_t mfma_ring_lds_bytes(int ksteps, bool rows);                         // LDS of a block: data ring + window of sums
-void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds_bytes, hipStream_t stream, bool rows);
+size_t mfma_ring_lds_bytes(int ksteps, bool rows, bool u8);                // LDS of a block: data ring + window of sums
+void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds_bytes, hipStream_t stream, bool rows, bool u8);
 
 }  // namespace iqa

@@ -215,7 +215,8 @@ class MfmaPlan:
 
 
 def mfma_supported(plan: ChannelPlan) -> bool:
-    return plan.fmt == "s16" and plan.taps_natural is not None
+    """int16 captures (every matrix-core kernel) and uint8 captures (the row-staged ring kernel only)."""
+    return plan.fmt in ("s16", "u8") and plan.taps_natural is not None
 
 
 @functools.lru_cache(maxsize=32)
@@ -254,7 +255,7 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
     several k-step ranges; every (group, range) is one pass of the kernel.
     """
     if not mfma_supported(plan):
-        raise ValueError("MFMA channelizer needs an int16 capture")
+        raise ValueError("MFMA channelizer needs an int16 or uint8 capture")
     g = plan.taps_natural
     D = plan.decimation
     n_groups = max(1, -(-(-(-plan.ntaps // D)) // MFMA_Q))
@@ -294,8 +295,10 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
         for ci in range(n_chunks):
             k0, k1 = bounds[ci], bounds[ci + 1]
             sl = t[:, 32 * k0 : 32 * k1]
-            passes.append(MfmaPass(gi, k0, k1 - k0, 128.0 * float(sl[:MFMA_Q].sum(dtype=np.int64)),
-                                   128.0 * float(sl[MFMA_Q:].sum(dtype=np.int64))))
+            # int16 data are split v = 256*hi + lo' + 128: the 128 makes a constant 128*sum(T); uint8 data have one piece
+            bias = 128.0 if plan.fmt == "s16" else 0.0
+            passes.append(MfmaPass(gi, k0, k1 - k0, bias * float(sl[:MFMA_Q].sum(dtype=np.int64)),
+                                   bias * float(sl[MFMA_Q:].sum(dtype=np.int64))))
     return MfmaPlan(ksteps, groups, passes)
 
 

@@ -179,15 +179,16 @@ class _ChannelKernel:
         self.last_kernel = "k_channelize_v1"
         self._ring_bytes = int(N.lib().iqa_mfma_ring_bytes(plan.decimation)) if plan.fmt == "s16" else 0
         # which ring kernel covers this decimation: 1 = contiguous slots (all k steps in one pass), 2 = row-staged slots
-        # (any D, k-step ranges of <= RING_ROWS_KSTEPS, int32 sums only), 0 = none -> the per-lane kernel
+        # (any D, k-step ranges of <= RING_ROWS_KSTEPS, int32 sums only; the only form for uint8 captures), 0 = none ->
+        # the per-lane kernel (int16) or the VALU kernel (uint8)
         ks_all = -(-2 * plan.decimation // 32)
         self._ring_mode = 0
-        if plan.fmt == "s16" and self.mfma_variant == "ring":
-            acc32 = int(bool(self.ring_acc32))
-            self._ring_mode = int(N.lib().iqa_mfma_ring_mode(plan.decimation, 0, ks_all, acc32))
+        if plan.fmt in ("s16", "u8") and self.mfma_variant == "ring":
+            acc32, code = int(bool(self.ring_acc32)), P.FMT_CODE[plan.fmt]
+            self._ring_mode = int(N.lib().iqa_mfma_ring_mode(code, plan.decimation, 0, ks_all, acc32))
             if self._ring_mode == 0:
-                self._ring_mode = int(N.lib().iqa_mfma_ring_mode(plan.decimation, 0, min(ks_all, self.RING_ROWS_KSTEPS), acc32))
-        self._mfma_ok = bool(self.use_mfma and P.mfma_supported(plan))
+                self._ring_mode = int(N.lib().iqa_mfma_ring_mode(code, plan.decimation, 0, min(ks_all, self.RING_ROWS_KSTEPS), acc32))
+        self._mfma_ok = bool(self.use_mfma and P.mfma_supported(plan) and (plan.fmt == "s16" or self._ring_mode == 2))
 
     def _ensure_mfma(self):
         with self._lock:
@@ -211,7 +212,7 @@ class _ChannelKernel:
                 rng = self._range_max(ps.k_count, variant)
                 self._pass_variant = getattr(self, "_pass_variant", []) + [variant]
                 self.mfma_params.append(N.MfmaParams(
-                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.ring_acc32) else 0), unit=mp.groups[ps.group].unit, c_re=ps.c_re,
+                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.ring_acc32) else 0), unit=mp.groups[ps.group].unit / (256.0 if self.plan.fmt == "u8" else 1.0), c_re=ps.c_re,
                     c_im=ps.c_im, debug_stamps=None, q_group=ps.group, k_first=ps.k_first, k_count=ps.k_count,
                     finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
@@ -296,7 +297,7 @@ class _ChannelKernel:
             big, big_frames, big_consumed = raw_dev, n_frames, consumed
             if halo is not None:  # the matrix-core kernels address the enclosing buffer
                 big, lead = halo
-                big_frames, big_consumed = int(big.numel()) // 2, consumed - int(lead)
+                big_frames, big_consumed = int(big.numel()) // 2, consumed - int(lead)  # 2 values per frame (I, Q)
             m_a, m_b = self._interior(big_consumed, big_frames, m_first, n_out)
             if m_b - m_a >= self.mfma_min_outputs:
                 self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
@@ -456,7 +457,7 @@ class Channelizer:
         if n == 0:
             return D.like_input(D.empty(0, "complex64"), raw)
         m_first, n_out = self.outputs_for(n)
-        if halo is not None and (self.fmt != "s16" or not D.is_tensor(raw)):
+        if halo is not None and (self.fmt not in ("s16", "u8") or not D.is_tensor(raw)):
             halo = None
         z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo)
              if n_out else D.empty(0, "complex64"))
@@ -530,7 +531,7 @@ class MixSignProbe:
             # initial state nor anything past the snippet: when the warm-up buffer is longer than the snippet they are
             # all interior outputs of the matrix-core kernel -- one launch per sign instead of three.
             z_keep = D.empty(n_z - discard, "complex64")
-            if fmt == "s16" and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
+            if fmt in ("s16", "u8") and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
                 _mean_power_into(z_keep, 0, self._powers[i : i + 1])
                 self._valid[i] = True
                 continue

@@ -742,6 +742,47 @@ def test_mfma_ring_kernel_matches_the_per_lane_kernel(A, fs, d, bw, n, acc32):
         assert rms(ring - ref) < tol[0] * scale and np.abs(ring - ref).max() < tol[1] * scale, other
 
 
+@pytest.mark.parametrize("fs,d,bw,n", [(2.4e6, 25, 12500.0, 6_000_000), (10e6, 104, 12500.0, 9_000_000), (50e6, 521, 12500.0, 16_000_000)])
+def test_mfma_ring_kernel_uint8_captures(A, fs, d, bw, n):
+    """uint8 I/Q captures (cu8, RTL-SDR style: 2.4 MS/s -> D = 25, an odd row of 50 bytes) on the matrix cores: the
+    row-staged ring kernel with one data piece (u ^ 0x80, two MFMAs per k step) against the float32 VALU kernel and the
+    oracle.  Also D = 104 and the three-pass D = 521 shape.  Bit-reproducible; error at the tap-quantisation floor."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import processing as PR
+
+    f_off = 25e3
+    s16 = O.synth_capture_s16(fs, n / fs, f_off).reshape(-1)
+    raw = ((s16.astype(np.int32) >> 8) + 128).astype(np.uint8)
+    taps = A.design_channel_filter(fs, bw, d)
+    x = D.to_device(raw, "uint8")
+    old_min, old_use = PR._ChannelKernel.mfma_min_outputs, PR._ChannelKernel.use_mfma
+    outs = {}
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 4096
+        for use in (False, True, True):
+            PR._ChannelKernel.use_mfma = use
+            ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt="u8")
+            cut = 2 * (n // 3 + 1)
+            z = torch.cat([ch.process(x[:cut]), ch.process(x[cut:])])  # second block: history + decimator phase
+            assert ch._kernel.last_kernel == ("k_channelize_mfma_s16_ring" if use else "k_channelize_v1")
+            outs.setdefault(use, []).append(z)
+    finally:
+        PR._ChannelKernel.mfma_min_outputs, PR._ChannelKernel.use_mfma = old_min, old_use
+    assert torch.equal(outs[True][0], outs[True][1])
+    valu, mfma = outs[False][0].cpu().numpy(), outs[True][0].cpu().numpy()
+    assert valu.shape == mfma.shape == (-(-n // d),)
+    n_cpu = min(n, 1_500_000)
+    want = O.decimate(O.overlap_save(O.nco_mix(O.ingest_to_complex64(raw[: 2 * n_cpu], "u8"), O.NcoState(f_off, fs), 1),
+                                     O.OverlapSaveState(taps, 65536)), O.DecimState(d))
+    k = want.size
+    grow = max(1.0, float(np.sqrt(len(taps) / 6401.0)))
+    assert rms(valu[:k] - want) < 2e-7
+    assert rms(mfma[:k] - want) < 1.4e-5 * grow and np.abs(mfma[:k] - want).max() < 1e-4 * grow
+    assert rms(mfma - valu) < 1.4e-5 * grow and np.abs(mfma - valu).max() < 1e-4 * grow
+
+
 def test_multi_channel_single_pass_and_cli(A, tmp_path):
     """BASELINE config 3 pattern: several --ft targets (mixed demodulators, bandwidths) extracted from ONE pass
     over the capture; every channel must equal its own single-target oracle run, and the CLI shim must
