@@ -260,7 +260,8 @@ class _ChannelKernel:
 
     def _mfma_passes(self, raw_dev, n_frames: int, consumed: int, m_a: int, n_int: int, out_dev, min_block: int = 512):
         mp = self._ensure_mfma()
-        self.last_kernel = "k_channelize_mfma_s16" + ("_ring" if self._pass_variant[-1] == "ring" else "")
+        self.last_kernel = ("k_channelize_mfma_u8" if self.plan.fmt == "u8" else "k_channelize_mfma_s16") + (
+            "_ring" if self._pass_variant[-1] == "ring" else "")
         partial = D.empty(2 * n_int, "float64") if len(mp.passes) > 1 else None
         for i, (ps, prm) in enumerate(zip(mp.passes, self.mfma_params)):
             last = i == len(mp.passes) - 1

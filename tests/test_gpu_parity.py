@@ -766,7 +766,7 @@ def test_mfma_ring_kernel_uint8_captures(A, fs, d, bw, n):
             ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt="u8")
             cut = 2 * (n // 3 + 1)
             z = torch.cat([ch.process(x[:cut]), ch.process(x[cut:])])  # second block: history + decimator phase
-            assert ch._kernel.last_kernel == ("k_channelize_mfma_s16_ring" if use else "k_channelize_v1")
+            assert ch._kernel.last_kernel == ("k_channelize_mfma_u8_ring" if use else "k_channelize_v1")
             outs.setdefault(use, []).append(z)
     finally:
         PR._ChannelKernel.mfma_min_outputs, PR._ChannelKernel.use_mfma = old_min, old_use
