@@ -42,8 +42,14 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # Defaults long enough to time the SUSTAINED rate: after an idle->load edge the part runs ~8 captures at boost
+    # clocks, overshoots its 1400 W package limit, is clamped for ~25 captures (channelizer 0.84 ms instead of 0.57)
+    # and settles by capture ~40 (profiles/power_trace.sh); 100 + 1000 captures take 0.8 s.
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle", type=int, default=60,
+                    help="the untimed phase is at least this many captures long: max(0, settle - warmup) extra untimed "
+                         "captures run in front of the warm-up steps (the power-management transient above)")
     ap.add_argument("--seconds", type=float, default=60.0, help="capture length (config 2: 60 s)")
     ap.add_argument("--sample-rate", type=float, default=10e6)
     ap.add_argument("--unique-seconds", type=float, default=5.0, help="seed-42 prefix generated on the host, then tiled")
@@ -104,15 +110,18 @@ def main() -> None:
     # finished 48 kHz PCM16 audio of every capture is gathered on rank 0 (as bytes: RCCL has no int16 type)
     gathered = [torch.empty(2 * n48, dtype=torch.uint8, device=D.device()) for _ in range(world)] if (world > 1 and rank == 0) else None
     pending = []
-    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
-    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + args.warmup)]
+    settle = max(0, args.settle - args.warmup)
+    n_untimed = settle + args.warmup
+    ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + n_untimed)]
+    ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + n_untimed)]
     tickets = []
 
     def step(i: int):
-        t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]), enclosing=buf, lead_frames=lead)
+        # resident: the capture was complete in HBM before the timed region (the metric's premise)
+        t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]), enclosing=buf, lead_frames=lead, resident=True)
         tickets.append(t)
         if world > 1:
-            runner.egress.wait_event(t["tail_done"])  # this capture's PCM16 is complete
+            runner.egress.wait_event(runner.tail_event(t))  # this capture's PCM16 is complete
             with torch.cuda.stream(runner.egress):    # the gather overlaps the next capture's kernels
                 while pending:
                     pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
@@ -130,21 +139,23 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-        if i == args.warmup - 2:
-            fence()  # one untimed step runs right after a fence, exactly like the first timed step will
-    fence()
-    stats0 = torch.cuda.memory_stats()
     import gc
 
+    # Everything slow on the host happens BEFORE the first capture: a generation-2 collection in the middle of a 0.7 ms
+    # step is a 10-70 ms stall, and that much idle GPU starts the power-management transient all over again.
     gc.collect()
-    gc.disable()  # a generation-2 collection in the middle of a 1.3 ms step shows up as a 10-50 ms stall
+    gc.disable()
+    for i in range(n_untimed):
+        if i == n_untimed - 2:
+            fence()  # one untimed step runs right after a fence, exactly like the first timed step will
+        step(i)
+    stats0 = torch.cuda.memory_stats()
+    fence()
     t0 = time.perf_counter()
     marks = []
     last = None
     for i in range(args.steps):
-        last = step(args.warmup + i)
+        last = step(n_untimed + i)
         marks.append(time.perf_counter() - t0)
     res = runner.collect(last)
     fence()
@@ -152,7 +163,7 @@ def main() -> None:
     if os.environ.get("IQA_BENCH_DEBUG"):
         stats1 = torch.cuda.memory_stats()
         keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")
-        print("host-side step completion times (ms):", [round(m * 1e3, 2) for m in marks],
+        print("host-side step completion times (ms):", [round(m * 1e3, 2) for m in marks[:80]],
               "after fence:", round((time.perf_counter() - t0) * 1e3, 2),
               "allocator deltas:", {k: stats1.get(k, 0) - stats0.get(k, 0) for k in keys}, file=sys.stderr)
     elapsed = time.perf_counter() - t0
@@ -161,7 +172,14 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = [ev_k0[args.warmup + i].elapsed_time(ev_k1[args.warmup + i]) for i in range(args.steps)]
+    kern_ms = [ev_k0[n_untimed + i].elapsed_time(ev_k1[n_untimed + i]) for i in range(args.steps)]
+    if os.environ.get("IQA_BENCH_DEBUG"):
+        # GPU-side series over warm-up + timed steps: period between consecutive channelizer starts, channelizer time
+        n_all = n_untimed + args.steps
+        period = [ev_k0[i].elapsed_time(ev_k0[i + 1]) for i in range(n_all - 1)]
+        kern = [ev_k0[i].elapsed_time(ev_k1[i]) for i in range(n_all)]
+        pick = sorted(set(list(range(0, min(n_all - 1, 40))) + list(range(40, n_all - 1, max(1, n_all // 60)))))
+        print("step: period_ms kernel_ms", " | ".join(f"{i}: {period[i]:.3f} {kern[i]:.3f}" for i in pick), file=sys.stderr)
     kern_avg_ms = float(np.mean(kern_ms))
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_total / (elapsed / args.steps) / 1e6  # MS/s, whole job
@@ -198,6 +216,7 @@ def main() -> None:
             "parallelism": f"{world} independent capture(s), one per GPU; RCCL gather of 48 kHz audio only",
             "audio_samples_48k": int(n48),
             "mix_sign": int(sign),
+            "settle_steps": settle,
         },
         "roofline": {
             "bound": "hbm",

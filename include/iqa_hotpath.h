@@ -180,6 +180,8 @@ int iqa_decimate(const void *in_dev, int64_t n, int64_t first, int32_t D, void *
                  void *stream);
 
 /* mean(|z|^2) over z[skip:n] accumulated in float64 into *power_dev (double[1], overwritten).
+ * Up to 65536 samples (the mixer-sign probes) one workgroup WRITES the result -- no memset, no atomics -- so
+ * power_dev may then be mapped pinned host memory (the probe's read-back without a copy).
  * ref: choose_mix_sign, processing.py:650-658; baseband_power, processing.py:1105. */
 int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *power_dev, void *stream);
 
@@ -255,9 +257,11 @@ int iqa_writer_clip(const void *a_dev, int64_t n, void *peak_dev, const void *se
  * BUILD-DEFINED SPEC (the reference's is libswresample: parity unpinned).      *
  *   y[j] = sum_t table[p][t] * x[q - (t - T)],  c = (j0+j)*down, q = c / up, p = c % up          *
  * table_dev: double[up][2T+1] polyphase rows; x zero outside [0, n_in).       *
+ * y_dev: float32[n_out] and/or pcm16_dev: int16[n_out] = iqa_float_to_pcm16 of the float32 value (the writer's    *
+ * `-acodec pcm_s16le` leg in the same pass); either may be NULL, not both.                                       *
  * ------------------------------------------------------------------------- */
 int iqa_resample(const void *x_dev, int64_t n_in, const void *table_dev, int32_t up, int32_t down, int32_t T,
-                 int64_t j0, int64_t n_out, void *y_dev, void *stream);
+                 int64_t j0, int64_t n_out, void *y_dev, void *pcm16_dev, void *stream);
 
 /* float32 -> PCM16 (round-half-even of y*32768, saturated).  Build-defined, see above. */
 int iqa_float_to_pcm16(const void *y_dev, int64_t n, void *pcm_dev, void *stream);

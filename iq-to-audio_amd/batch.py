@@ -23,12 +23,16 @@ class ResidentCaptureRunner:
     ``-ar 48000 pcm_s16le`` leg for one capture per ``submit`` -- queued without any host<->device
     synchronisation, so consecutive captures overlap on the GPU:
 
-    * the two mixer-sign probes (``choose_mix_sign``, processing.py:623-663) and, right behind them, the
-      channelizer run *speculatively* for sign +1 -- the reference's tie-break and the common case (a signal
+    * compute stream: the two mixer-sign probes (``choose_mix_sign``, processing.py:623-663) and, right behind them,
+      the channelizer run *speculatively* for sign +1 -- the reference's tie-break and the common case (a signal
       at +f_off lands at DC with sign +1) -- then demodulator + writer clip + 48 kHz
       resample + PCM16;
     * egress stream: D2H of the PCM16 into pinned memory (and whatever the caller chains on ``done``),
-      beside the next capture's kernels.
+      beside the next capture's channelizer;
+    * aux stream, ``submit(..., resident=True)`` only: everything of a capture that depends on nothing but the capture
+      itself -- both probes, the decoder-state reset, the float32 launch for the filter's start-up outputs -- runs
+      beside the PREVIOUS capture's demodulator/resampler, so the compute stream holds nothing but channelizer,
+      demodulator and resampler back to back.
 
     ``collect`` waits for a capture, reads the probe back and, if it chose -1 after all, re-runs that capture
     with the right sign before returning.  Nothing is cached between captures except the plans.
@@ -38,7 +42,7 @@ class ResidentCaptureRunner:
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
-                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, tail_stream: bool = False, probe_stream: bool = False):
+                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None):
         torch = D.torch_mod()
         self.taps, self.fs, self.f_off, self.d, self.fs_ch = np.asarray(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
         self.chunk, self.n_frames, self.fmt, self.iq_order = int(chunk), int(n_frames), fmt, iq_order
@@ -48,17 +52,12 @@ class ResidentCaptureRunner:
         self.starts = P.chunk_output_starts(self.chunk, self.d, 0, self.n_frames)
         self.rs = Resampler48k(self.fs_ch)
         self.n48 = self.rs.plan.n_out(self.n_dec)
+        # One compute stream.  A second one for demod/resample beside the next channelizer was measured and dropped
+        # (-6 % per capture at best while stretching the channelizer by 40 %: the small kernels take its CU slots).
         self.compute = torch.cuda.current_stream()
-        # tail_stream=True puts demod/resample/PCM16 and the probes on a second stream.  Measured on MI355X it buys
-        # ~6 % per capture at best while stretching the channelizer by 40 % (the small kernels steal its CU slots),
-        # so the default keeps one compute stream; only the D2H runs beside it.
-        self.tail = torch.cuda.Stream() if tail_stream else self.compute
         self.egress = torch.cuda.Stream()
-        # probe_stream=True runs the probes (off the critical path: the channelizer is speculative) on their own stream,
-        # gated to start when the previous capture's channelizer has finished.  Measured: no gain -- whatever part of
-        # them is caught beside the next channelizer is starved and stretches it by 10 % -- so it is off by default.
-        self.probe_stream = torch.cuda.Stream() if probe_stream else None
-        self._ring_done = None
+        self.aux = torch.cuda.Stream()
+        self._ring_done = None  # event behind the most recent channelizer launch (the aux stream starts from there)
         self.slots = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
                            pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(), busy=None,
                            dem=ChannelDemod(demod_mode, self.fs_ch, deemph_us=deemph_us, agc_enabled=agc_enabled))
@@ -67,43 +66,70 @@ class ResidentCaptureRunner:
         self._egress_pending = None  # ticket whose D2H has not been queued yet (see _flush_egress)
         self.egress_workgroups = 8
 
-    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None):
+    def _probe(self, raw_dev, resident: bool):
+        if self.override is not None:
+            return None
+        torch = D.torch_mod()
+        warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
+        # record_done=False: the events that lie behind the probes are the capture's own (set in _chain) -- an event
+        # record between two kernels of a stream costs ~7 us on this part
+        with torch.cuda.stream(self.aux if resident else self.compute):
+            return MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order,
+                                record_done=False)
+
+    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None, resident: bool = False, probe=None):
         """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
         torch = D.torch_mod()
         chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
                            fmt=self.fmt, iq_order=self.iq_order)
         chan.plan_ahead()
         dem = slot["dem"]
-        with torch.cuda.stream(self.tail):
+        side = self.aux if resident else None
+        with torch.cuda.stream(self.aux if resident else self.compute):
             dem.reset()
-            dem.prepare(self.n_dec, self.starts)
-        gate = torch.cuda.Event()
-        gate.record()  # compute stream: behind this capture's probes, in front of its channelizer
+        dem.prepare(self.n_dec, self.starts)
+        # gate: compute stream, behind this capture's probes (if they are there), in front of its channelizer -- the
+        # caller's timing event when there is one (it is recorded exactly there)
+        gate = None
+        if events is None:
+            gate = torch.cuda.Event()
+            gate.record()
         prev = self._egress_pending
-        chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo)
-        if self.probe_stream is not None:
-            self._ring_done = torch.cuda.Event()
-            self._ring_done.record()
+        chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo, edge_stream=side)
+        if events is None:
+            ring_done = torch.cuda.Event()
+            ring_done.record()
+        else:
+            gate, ring_done = events[0], events[1]
+        self._ring_done = ring_done
         if prev is not None:
             self._flush_egress(gate)  # the previous capture's D2H runs beside the channelizer, not beside the probes
-        if self.tail is not self.compute:
-            z_ready = torch.cuda.Event()
-            z_ready.record()
-            self.tail.wait_event(z_ready)
-        with torch.cuda.stream(self.tail):
-            dem.process(slot["z"], self.starts, slot["audio"])
-            y48 = self.rs.process(slot["audio"])
-            pcm = self.rs.to_pcm16(y48)
-            tail_done = torch.cuda.Event()
-            tail_done.record()
+        aux_done = None
+        if resident:
+            aux_done = torch.cuda.Event()
+            aux_done.record(self.aux)
+            self.compute.wait_event(aux_done)  # start-up outputs and decoder state are in place (long ago)
+        if probe is not None:
+            probe._done = [aux_done] if resident else [gate]
+        dem.process(slot["z"], self.starts, slot["audio"])
+        pcm = self.rs.process(slot["audio"], want="pcm16")  # the float32 48 kHz stream is never stored
         done = torch.cuda.Event()
-        ticket = dict(chan=chan, dem=dem, pcm=pcm, y48=y48, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel,
-                      slot=slot, egress_queued=False)
+        # tail_done: recorded lazily (tail_event) -- the next capture's gate lies behind it anyway
+        ticket = dict(chan=chan, dem=dem, pcm=pcm, done=done, tail_done=None, kernel=chan._kernel.last_kernel,
+                      slot=slot, egress_queued=False, resident=resident)
         self._egress_pending = ticket
         return ticket
 
+    def tail_event(self, ticket: dict):
+        """Event behind the last kernel of ``ticket``'s capture (its PCM16 is complete in device memory)."""
+        if ticket.get("tail_done") is None:
+            ev = D.torch_mod().cuda.Event()
+            ev.record(self.compute)
+            ticket["tail_done"] = ev
+        return ticket["tail_done"]
+
     def _flush_egress(self, gate=None) -> None:
-        """Queue the D2H of the capture whose PCM16 is ready (or will be, behind its tail_done event).  Called right
+        """Queue the D2H of the capture whose PCM16 is ready (or will be, behind its tail event).  Called right
         before the next capture's channelizer is launched, gated on an event behind that capture's probes, so the
         copy kernel -- whose waves sit on PCIe stores -- shares the GPU with the long HBM-bound kernel instead of the
         small latency-bound ones (measured: a probe beside the copy takes 120 us instead of 20); from ``collect``,
@@ -112,9 +138,10 @@ class ResidentCaptureRunner:
         if t is None or t["egress_queued"]:
             return
         torch = D.torch_mod()
-        self.egress.wait_event(t["tail_done"])
         if gate is not None:
-            self.egress.wait_event(gate)
+            self.egress.wait_event(gate)  # (behind the capture's last kernel too: same stream, recorded later)
+        else:
+            self.egress.wait_event(self.tail_event(t))
         with torch.cuda.stream(self.egress):
             t["pcm"].record_stream(self.egress)
             host = t["slot"]["pcm_host"]
@@ -134,34 +161,30 @@ class ResidentCaptureRunner:
         ksteps = -(-2 * decimation // 32)
         return 0, 512 * ksteps + 34 * decimation
 
-    def submit(self, raw_dev, events=None, enclosing=None, lead_frames: int = 0) -> dict:
+    def submit(self, raw_dev, events=None, enclosing=None, lead_frames: int = 0, resident: bool = False) -> dict:
         """Queue one capture (device tensor of interleaved frames, ``n_frames`` long).  Returns a ticket for ``collect``.
         ``enclosing``/``lead_frames``: ``raw_dev`` is ``enclosing[2*lead_frames : 2*(lead_frames + n_frames)]``; frames
         behind the capture may be read, ``lead_frames`` frames in front of it (if any) must be zeros
-        (see ``padded_capture_frames``)."""
+        (see ``padded_capture_frames``).  ``resident=True``: the capture's bytes are complete in device memory NOW
+        (uploaded and synchronised before this call, not still being produced on a stream), so the launches that
+        depend on nothing else may run on the aux stream, ahead of the compute stream.  ``events``: optional pair of
+        torch events recorded directly in front of / behind the channelizer's dominant launch."""
+        torch = D.torch_mod()
+        if torch.cuda.current_stream() != self.compute:
+            raise RuntimeError("submit() must be called with the stream the runner was created on as the current stream")
         slot = self.slots[self._next % self.SLOTS]
         self._next += 1
         if slot["busy"] is not None:  # the slot's buffers are still owned by an earlier, uncollected capture
             self.collect(slot["busy"])
-        torch = D.torch_mod()
-        if slot.get("tail_done") is not None and self.tail != torch.cuda.current_stream():
-            torch.cuda.current_stream().wait_event(slot["tail_done"])  # z/audio of this slot are free again
-        probe = None
-        if self.override is None:
-            warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
-            ps = self.probe_stream if self.probe_stream is not None else self.tail
-            if ps != torch.cuda.current_stream():  # raw_dev was produced on the caller's stream
-                ready = torch.cuda.Event()
-                ready.record()
-                ps.wait_event(ready)
-            if self.probe_stream is not None and self._ring_done is not None:
-                ps.wait_event(self._ring_done)
-            with torch.cuda.stream(ps):
-                probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order)
+        if resident and self._ring_done is not None:
+            # behind the previous channelizer: what runs on the aux stream shares the GPU with the previous capture's
+            # short kernels, not with a channelizer (small kernels beside it starve and stretch it); the earlier user
+            # of this slot's buffers finished before that
+            self.aux.wait_event(self._ring_done)
+        probe = self._probe(raw_dev, resident)
         sign = self.override if self.override is not None else 1
         halo = (enclosing, int(lead_frames)) if enclosing is not None else None
-        ticket = self._chain(raw_dev, slot, sign, events, halo)
-        slot["tail_done"] = ticket["tail_done"]
+        ticket = self._chain(raw_dev, slot, sign, events, halo, resident, probe)
         ticket.update(probe=probe, sign=sign, raw=raw_dev, halo=halo)
         slot["busy"] = ticket
         return ticket
@@ -180,13 +203,12 @@ class ResidentCaptureRunner:
             if sign != ticket["sign"]:  # the speculation was wrong: this capture again, with the sign the probe chose
                 ticket["done"].synchronize()
                 probe, raw = ticket["probe"], ticket["raw"]
-                redo = self._chain(raw, slot, sign, None, ticket.get("halo"))
+                redo = self._chain(raw, slot, sign, None, ticket.get("halo"), ticket.get("resident", False))
                 self._flush_egress()
-                slot["tail_done"] = redo["tail_done"]
                 ticket.update(redo, sign=sign, probe=probe, raw=raw)
         ticket["done"].synchronize()
         ticket["collected"] = True
-        ticket["raw"] = ticket["pcm"] = ticket["y48"] = None  # back to the allocator: the next capture reuses them
+        ticket["raw"] = ticket["pcm"] = None  # back to the allocator: the next capture reuses them
         if slot["busy"] is ticket:
             slot["busy"] = None
         ticket["result"] = dict(pcm_host=slot["pcm_host"], sign=int(sign), audio=slot["audio"], z=slot["z"],

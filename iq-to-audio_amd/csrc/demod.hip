@@ -341,12 +341,18 @@ __global__ __launch_bounds__(256) void k_writer_clip(const float *a, long long n
     }
 }
 
+// -acodec pcm_s16le: round-half-even(y * 32768), saturated
+__device__ __forceinline__ short pcm16_of(float y)
+{
+    const double v = rint(static_cast<double>(y) * 32768.0);
+    return static_cast<short>(fmin(fmax(v, -32768.0), 32767.0));
+}
+
 __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 {
     const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double v = rint(static_cast<double>(y[i]) * 32768.0);
-    pcm[i] = static_cast<short>(fmin(fmax(v, -32768.0), 32767.0));
+    pcm[i] = pcm16_of(y[i]);
 }
 
 // 48 kHz polyphase resampler, float64 accumulate.  Row-stationary: outputs J and J+up use the same polyphase
@@ -362,7 +368,7 @@ constexpr int RS_LANES = 4;  // lanes per output
 template <int NI>  // taps per lane = ceil(row_len / 4)
 __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
                                                                int down, int T, long long j0, long long n_out, float *y,
-                                                               int split)
+                                                               short *pcm, int split)
 {
     const int lane = threadIdx.x & 63, sub = lane & (RS_LANES - 1), slot = lane >> 2;
     const long long wid = static_cast<long long>(blockIdx.x) * RS_WAVES + (threadIdx.x >> 6);
@@ -412,7 +418,11 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
         }
         acc += __shfl_xor(acc, 2, kWave);
         acc += __shfl_xor(acc, 1, kWave);  // stays inside the quad
-        if (jj < n_out && sub == 0) y[jj] = static_cast<float>(acc);
+        if (jj < n_out && sub == 0) {
+            const float v = static_cast<float>(acc);
+            if (y != nullptr) y[jj] = v;
+            if (pcm != nullptr) pcm[jj] = pcm16_of(v);  // the writer's PCM16 leg in the same pass
+        }
     }
 }
 
@@ -577,11 +587,11 @@ extern "C" int iqa_writer_clip(const void *a_dev, int64_t n, void *peak_dev, con
 }
 
 extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_dev, int32_t up, int32_t down,
-                            int32_t T, int64_t j0, int64_t n_out, void *y_dev, void *stream)
+                            int32_t T, int64_t j0, int64_t n_out, void *y_dev, void *pcm16_dev, void *stream)
 {
     if (n_in < 0 || n_out < 0 || j0 < 0 || up < 1 || down < 1 || T < 0) return fail_inval("bad resampler sizes");
     if (n_out == 0) return IQA_OK;
-    if (!table_dev || !y_dev || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
+    if (!table_dev || (!y_dev && !pcm16_dev) || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
     if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
     const int64_t g_total = (n_out + up - 1) / up;  // outputs per polyphase row
     // enough waves to fill the chip (>= ~8 per SIMD) while a wave still amortises its 4*NI tap loads over several steps
@@ -592,7 +602,7 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
 #define IQA_RS_LAUNCH(NI)                                                                                          \
     hipLaunchKernelGGL((k_resample<NI>), grid, block, 0, as_stream(stream), static_cast<const float *>(x_dev),     \
                        (long long)n_in, static_cast<const double *>(table_dev), (int)up, (int)down, (int)T,        \
-                       (long long)j0, (long long)n_out, static_cast<float *>(y_dev), split)
+                       (long long)j0, (long long)n_out, static_cast<float *>(y_dev), static_cast<short *>(pcm16_dev), split)
     if (ni <= 17) IQA_RS_LAUNCH(17);
     else if (ni <= 24) IQA_RS_LAUNCH(24);
     else if (ni <= 32) IQA_RS_LAUNCH(32);

@@ -213,10 +213,18 @@ __global__ __launch_bounds__(FC_THREADS) void k_fused_carry(FusedArgs a)
         }
     }
     if (tid == FC_THREADS - 1) a.fin[0] = s;  // runs past the end are identity maps: the last thread holds the total
+    // Snapshot of the incoming state for the apply pass (fin[1] = prev, fin[2] = st[0]): its last block hands the
+    // outgoing state to the next call while its first block may not have read the incoming one yet.
+    if (tid == 0) {
+        if (a.prev != nullptr) reinterpret_cast<float2 *>(a.fin + 1)[0] = a.prev[0];
+        if (a.st != nullptr) a.fin[2] = a.st[0];
+    }
 }
 
+// `a.prev` / `a.st` point at the carry pass's snapshot; prev_out / st_out at the caller's state block (written by
+// the last block: the streaming state for the next call, OP != F_AGC)
 template <int OP, int SRC, int SINK>
-__global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
+__global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a, float2 *prev_out, double *st_out)
 {
     __shared__ Aff s_w[SC_THREADS / kWave];
     __shared__ float s_pk[SC_THREADS / kWave];
@@ -337,6 +345,18 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
             if (simple) atomicAdd(&a.sumsq[seg1 * IQA_SUMSQ_SLOTS + sub], s_sq[4] + s_sq[5] + s_sq[6] + s_sq[7]);
         }
     }
+    if (OP != F_AGC && blockIdx.x == a.nblocks - 1 && tid == 0) {  // hand the streaming state to the next call
+        if constexpr (SRC == S_QUAD) prev_out[0] = a.z[a.n - 1];
+        if constexpr (OP == F_DEEMPH) {
+            st_out[0] = a.fin[0];
+        } else if constexpr (OP == F_DC) {
+            float last;
+            if constexpr (SRC == S_F32) last = a.x[a.n - 1];
+            else last = src_value<SRC>(a, a.n - 1, a.z[a.n - 1], make_float2(0.f, 0.f));
+            st_out[0] = static_cast<double>(last);
+            st_out[1] = a.fin[0];
+        }
+    }
     // the audio goes out last: nothing waits for these stores (a barrier behind them would)
     if (a.y_aligned && base + SC_ITEMS <= a.n) {  // 32 contiguous, aligned bytes per thread: two 16-byte stores
         float4 *yp = reinterpret_cast<float4 *>(a.y + base);
@@ -346,23 +366,6 @@ __global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a)
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i)
             if (base + i < a.n) a.y[base + i] = vout[i];
-    }
-}
-
-// after apply: hand the streaming state to the next block
-template <int OP, int SRC>
-__global__ void k_fused_finish(FusedArgs a, float2 *prev_out, double *st_out)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if constexpr (SRC == S_QUAD) prev_out[0] = a.z[a.n - 1];
-    if constexpr (OP == F_DEEMPH) {
-        st_out[0] = a.fin[0];
-    } else if constexpr (OP == F_DC) {
-        float last;
-        if constexpr (SRC == S_F32) last = a.x[a.n - 1];
-        else last = src_value<SRC>(a, a.n - 1, a.z[a.n - 1], make_float2(0.f, 0.f));
-        st_out[0] = static_cast<double>(last);
-        st_out[1] = a.fin[0];
     }
 }
 
@@ -376,8 +379,10 @@ static int launch_fused(FusedArgs a, float2 *prev_out, double *st_out, void *wor
     a.fin = a.carry + a.nblocks;
     hipLaunchKernelGGL((k_fused_reduce<OP, SRC>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, a);
     hipLaunchKernelGGL((k_fused_carry<OP>), dim3(1), dim3(FC_THREADS), 0, s, a);
-    hipLaunchKernelGGL((k_fused_apply<OP, SRC, SINK>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, a);
-    if (OP != F_AGC) hipLaunchKernelGGL((k_fused_finish<OP, SRC>), dim3(1), dim3(1), 0, s, a, prev_out, st_out);
+    FusedArgs b = a;  // the apply pass reads the incoming state from the carry pass's snapshot
+    b.prev = reinterpret_cast<const float2 *>(a.fin + 1);
+    b.st = a.fin + 2;
+    hipLaunchKernelGGL((k_fused_apply<OP, SRC, SINK>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, b, prev_out, st_out);
     return check_launch("fused demodulator");
 }
 

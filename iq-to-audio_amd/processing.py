@@ -238,14 +238,17 @@ class _ChannelKernel:
                    c_int64(consumed), N.ptr(hist_dev), c_int64(m_first), c_int64(n_out), N.ptr(out_dev), N.stream_ptr())
 
     def run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev=None,
-            events=None, halo=None):
+            events=None, halo=None, edge_stream=None):
         """``events``: optional (start, stop) torch.cuda.Event pair recorded around the dominant launch.
         ``halo``: optional (buffer, lead_frames) -- ``raw_dev`` is the slice ``buffer[lead : lead + n_frames]`` (in
         frames) of a larger device buffer whose ``lead`` frames in front hold the history of this block (zeros at the
         start of a capture) and whose frames behind may be read (their values are never used): the matrix-core
-        kernels then cover the block's first and last outputs too and the two VALU edge launches disappear."""
+        kernels then cover the block's first and last outputs too and the two VALU edge launches disappear.
+        ``edge_stream``: optional torch stream for the small VALU launches of the block's first and last outputs (they
+        write their own part of ``out_dev``); the caller orders it against the producers of ``raw_dev`` and the
+        consumers of ``out_dev``."""
         with self._lock:
-            return self._run(raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev, events, halo)
+            return self._run(raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev, events, halo, edge_stream)
 
     def _interior(self, consumed: int, n_frames: int, m_first: int, n_out: int) -> tuple[int, int]:
         """Outputs [m_a, m_b) the matrix-core kernels can produce from this block's frames alone."""
@@ -290,7 +293,14 @@ class _ChannelKernel:
             self._mfma_passes(raw_dev, n_frames, 0, m_first, n_out, out_dev, min_block=64)
             return True
 
-    def _run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev, events, halo=None):
+    def _edges(self, edge_stream, *args):
+        if edge_stream is None:
+            return self._valu(*args)
+        with D.torch_mod().cuda.stream(edge_stream):
+            self._valu(*args)
+
+    def _run(self, raw_dev, n_frames: int, consumed: int, hist_dev, m_first: int, n_out: int, out_dev, events, halo=None,
+             edge_stream=None):
         if out_dev is None:
             out_dev = D.empty(n_out, "complex64")
         self.last_kernel = "k_channelize_v1"
@@ -301,13 +311,14 @@ class _ChannelKernel:
                 big_frames, big_consumed = int(big.numel()) // 2, consumed - int(lead)  # 2 values per frame (I, Q)
             m_a, m_b = self._interior(big_consumed, big_frames, m_first, n_out)
             if m_b - m_a >= self.mfma_min_outputs:
-                self._valu(raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
+                self._edges(edge_stream, raw_dev, n_frames, consumed, hist_dev, m_first, m_a - m_first, out_dev)
                 if events:
                     events[0].record()
                 self._mfma_passes(big, big_frames, big_consumed, m_a, m_b - m_a, out_dev[m_a - m_first :])
                 if events:
                     events[1].record()
-                self._valu(raw_dev, n_frames, consumed, hist_dev, m_b, m_first + n_out - m_b, out_dev[m_b - m_first :])
+                self._edges(edge_stream, raw_dev, n_frames, consumed, hist_dev, m_b, m_first + n_out - m_b,
+                            out_dev[m_b - m_first :])
                 return out_dev
         if events:
             events[0].record()
@@ -449,18 +460,18 @@ class Channelizer:
         m_end = -(-(self.consumed + n_frames) // d)
         return m_first, m_end - m_first
 
-    def process(self, raw, out_dev=None, events=None, last_block: bool = False, halo=None):
+    def process(self, raw, out_dev=None, events=None, last_block: bool = False, halo=None, edge_stream=None):
         """``raw``: interleaved frames (NumPy or device tensor, dtype of ``fmt``; complex64 for f32).
         Returns the decimated complex64 samples for this block.  ``last_block``: nothing follows, so the
-        L-1 frame history is not carried over (saves a launch for whole-capture calls).  ``halo``: see
-        ``_ChannelKernel.run`` (int16 device captures only)."""
+        L-1 frame history is not carried over (saves a launch for whole-capture calls).  ``halo``, ``edge_stream``:
+        see ``_ChannelKernel.run`` (int16 / uint8 device captures only)."""
         x, n = _as_frames(raw, self.fmt)
         if n == 0:
             return D.like_input(D.empty(0, "complex64"), raw)
         m_first, n_out = self.outputs_for(n)
         if halo is not None and (self.fmt not in ("s16", "u8") or not D.is_tensor(raw)):
             halo = None
-        z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo)
+        z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo, edge_stream)
              if n_out else D.empty(0, "complex64"))
         keep = 0 if last_block else self.ntaps - 1
         if keep:
@@ -504,8 +515,13 @@ class MixSignProbe:
     """``choose_mix_sign`` split into an asynchronous launch and a blocking ``result()``, so the
     caller can plan the channelizer while the two probes run."""
 
+    #: iqa_mean_power handles up to this many samples with its single-block, atomics-free kernel
+    DIRECT_MAX = 65536
+
     def __init__(self, warmup, sample_rate: float, freq_offset: float, taps: np.ndarray, decimation: int, *,
-                 fmt: str = "f32", iq_order: str = "iq"):
+                 fmt: str = "f32", iq_order: str = "iq", record_done: bool = True):
+        """``record_done=False``: the caller sets ``_done`` to event(s) of its own that lie behind both probes (an
+        event record between two kernels of a stream costs ~7 us on this part)."""
         self._powers = None
         self._valid = [False, False]
         x_all, n_in = _as_frames(warmup, fmt)
@@ -522,36 +538,48 @@ class MixSignProbe:
         self._host = _pinned_scalars(id(self))
         self._sign = None
         for i, sign in enumerate((1, -1)):
-            ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
-                             fmt=fmt, iq_order=iq_order)
-            n_z = -(-snippet_len // decim)
-            discard = min(ntaps, n_z // 4)
-            if n_z - discard == 0:
+            self._probe_one(i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)
+        self._done = None
+        if record_done:
+            self._done = D.torch_mod().cuda.Event()
+            self._done.record()
+
+    def _probe_one(self, i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order):
+        """Queue the probe for one mixer sign on the current stream; its mean power ends up in ``_host[i]``."""
+        ntaps = len(taps)
+        ch = Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim,
+                         fmt=fmt, iq_order=iq_order)
+        n_z = -(-snippet_len // decim)
+        discard = min(ntaps, n_z // 4)
+        if n_z - discard == 0:
+            discard = 0
+        # Only z[discard:] enters the power (processing.py:651-656), and those outputs see neither the zero
+        # initial state nor anything past the snippet: when the warm-up buffer is longer than the snippet they are
+        # all interior outputs of the matrix-core kernel -- one launch per sign instead of three.
+        z_keep = D.empty(n_z - discard, "complex64")
+        if fmt in ("s16", "u8") and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
+            # a short reduction is one block that WRITES its result: straight into the mapped pinned slot, no
+            # device scalar and no copy behind it (a blit between kernels costs ~13 us of a 0.9 ms capture)
+            direct = z_keep.numel() <= self.DIRECT_MAX
+            _mean_power_into(z_keep, 0, (self._host if direct else self._powers)[i : i + 1])
+            self._valid[i] = True
+            if not direct:
+                self._host[i : i + 1].copy_(self._powers[i : i + 1], non_blocking=True)
+            return
+        z = ch.process(x, last_block=True)
+        if z.numel():
+            discard = min(ntaps, z.numel() // 4)
+            if z.numel() - discard == 0:
                 discard = 0
-            # Only z[discard:] enters the power (processing.py:651-656), and those outputs see neither the zero
-            # initial state nor anything past the snippet: when the warm-up buffer is longer than the snippet they are
-            # all interior outputs of the matrix-core kernel -- one launch per sign instead of three.
-            z_keep = D.empty(n_z - discard, "complex64")
-            if fmt in ("s16", "u8") and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
-                _mean_power_into(z_keep, 0, self._powers[i : i + 1])
-                self._valid[i] = True
-                continue
-            z = ch.process(x, last_block=True)
-            if z.numel():
-                discard = min(ntaps, z.numel() // 4)
-                if z.numel() - discard == 0:
-                    discard = 0
-                _mean_power_into(z, discard, self._powers[i : i + 1])
-                self._valid[i] = True
-        self._host.copy_(self._powers, non_blocking=True)
-        self._done = D.torch_mod().cuda.Event()
-        self._done.record()
+            _mean_power_into(z, discard, self._powers[i : i + 1])
+            self._valid[i] = True
+            self._host[i : i + 1].copy_(self._powers[i : i + 1], non_blocking=True)
 
     def result(self) -> int:
         if self._powers is None:
             return 1
         if self._sign is None:
-            self._done.synchronize()
+            self._wait()
             host = self._host.numpy()
             best_sign, best_power = 1, -np.inf
             for i, sign in enumerate((1, -1)):
@@ -563,10 +591,15 @@ class MixSignProbe:
             self._host = None
         return self._sign
 
+    def _wait(self) -> None:
+        done = self._done
+        for ev in (done if isinstance(done, (list, tuple)) else [done]):
+            ev.synchronize()
+
     def __del__(self):
         try:
             if getattr(self, "_host", None) is not None and self._sign is None:
-                self._done.synchronize()  # the copy into the pinned buffer must not land in someone else's read-back
+                self._wait()  # the write into the pinned buffer must not land in someone else's read-back
                 _release_scalars(self._host)
         except Exception:
             pass
@@ -722,15 +755,20 @@ class Resampler48k:
         self.plan = P.plan_resampler(fs_channel)
         self.table_dev = D.from_numpy(self.plan.table.reshape(-1))
 
-    def process(self, audio_dev):
+    def process(self, audio_dev, *, want: str = "f32"):
+        """48 kHz audio of a whole stream: float32 (``want="f32"``), PCM16 (``"pcm16"``: what the WAV holds, rounded
+        from the float32 value in the same pass) or the pair (``"both"``)."""
+        if want not in ("f32", "pcm16", "both"):
+            raise ValueError(f"want must be 'f32', 'pcm16' or 'both', not {want!r}")
         n_in = int(audio_dev.numel())
         n_out = self.plan.n_out(n_in)
-        y = D.empty(n_out, "float32")
+        y = D.empty(n_out, "float32") if want != "pcm16" else None
+        pcm = D.empty(n_out, "int16") if want != "f32" else None
         if n_out:
             N.call("iqa_resample", N.ptr(audio_dev), c_int64(n_in), N.ptr(self.table_dev), c_int32(self.plan.up),
-                   c_int32(self.plan.down), c_int32(self.plan.half_taps), c_int64(0), c_int64(n_out), N.ptr(y),
+                   c_int32(self.plan.down), c_int32(self.plan.half_taps), c_int64(0), c_int64(n_out), N.ptr(y), N.ptr(pcm),
                    N.stream_ptr())
-        return y
+        return y if want == "f32" else pcm if want == "pcm16" else (y, pcm)
 
     @staticmethod
     def to_pcm16(y_dev):
@@ -946,7 +984,7 @@ class _Target:
         if self.owner.keep_channel_audio:
             self.owner.audio_fs_channel = audio
         rs = Resampler48k(self.fs_channel)
-        pcm = rs.to_pcm16(rs.process(audio)).cpu().numpy()
+        pcm = rs.process(audio, want="pcm16").cpu().numpy()
         iqio.write_wav_pcm16(self.output_path, pcm, 48_000)
         self.peak = self.demod.peak
         self.owner.chunk_rms_dbfs = self.demod.chunk_rms_dbfs()

@@ -410,6 +410,13 @@ def test_resampler_matches_spec(A):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=2e-7)
     pcm = rs.to_pcm16(y).cpu().numpy()
     np.testing.assert_array_equal(pcm, O.float_to_pcm16(y.cpu().numpy()))
+    # the one-pass forms: PCM16 straight from the resampler, alone and beside the float32 stream
+    y2, pcm2 = rs.process(D.to_device(x, "float32"), want="both")
+    np.testing.assert_array_equal(y2.cpu().numpy(), y.cpu().numpy())
+    np.testing.assert_array_equal(pcm2.cpu().numpy(), pcm)
+    np.testing.assert_array_equal(rs.process(D.to_device(x, "float32"), want="pcm16").cpu().numpy(), pcm)
+    with pytest.raises(ValueError):
+        rs.process(D.to_device(x, "float32"), want="s24")
     # C5's rate: gcd(48000, 95969) == 1
     rs5 = Resampler48k(50e6 / 521)
     y5 = rs5.process(D.to_device(x, "float32")).cpu().numpy()
@@ -451,11 +458,13 @@ def test_pipeline_end_to_end_wav(A, tmp_path):
         A.ProcessingPipeline(A.ProcessingConfig(in_path=wav, target_freq=4e8, center_freq=4e8, iq_order="xx")).run()
 
 
-def test_resident_capture_runner_batch_and_sign_speculation(A):
+@pytest.mark.parametrize("resident", [False, True])
+def test_resident_capture_runner_batch_and_sign_speculation(A, resident):
     """batch.ResidentCaptureRunner: a batch of device-resident captures with one set of settings, every
-    capture queued without a host sync (speculative mixer sign +1, tail on a second stream).  Each capture's
-    48 kHz PCM16 must equal the oracle's (<= 1 LSB), captures must not bleed into each other through the two
-    buffer slots, and a capture whose probe picks sign -1 must come out as if the sign had been known."""
+    capture queued without a host sync (speculative mixer sign +1; ``resident``: probes, decoder-state reset and the
+    start-up outputs on the aux stream, ahead of the compute stream).  Each capture's 48 kHz PCM16 must equal the
+    oracle's (<= 1 LSB), captures must not bleed into each other through the two buffer slots, and a capture whose
+    probe picks sign -1 must come out as if the sign had been known."""
     import torch
 
     from iq_to_audio_amd import _dev as D
@@ -474,7 +483,8 @@ def test_resident_capture_runner_batch_and_sign_speculation(A):
     runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
                                    n_frames=n, demod_mode="nfm")
     devs = [D.to_device(c.reshape(-1), "int16") for c in caps]
-    tickets = [runner.submit(x) for x in devs]   # submit 3 and 4 collect 1 and 2 to free their slots
+    torch.cuda.synchronize()  # resident=True promises complete captures
+    tickets = [runner.submit(x, resident=resident) for x in devs]   # submit 3 and 4 collect 1 and 2 to free their slots
     got = []
     for t in tickets:
         r = runner.collect(t)
@@ -490,7 +500,7 @@ def test_resident_capture_runner_batch_and_sign_speculation(A):
         assert pcm.size == ref48.size == runner.n48
         assert np.max(np.abs(pcm.astype(np.int32) - ref48.astype(np.int32))) <= 1
     # the mis-speculated capture, alone: same answer as the oracle that is told nothing about the sign
-    t = runner.submit(devs[1])
+    t = runner.submit(devs[1], resident=resident)
     r = runner.collect(t)
     want = O.run_chain(caps[1], sample_rate=fs, freq_offset=f_off, keep_decimated=False)
     assert r["sign"] == want.mix_sign == -1
@@ -501,12 +511,13 @@ def test_resident_capture_runner_batch_and_sign_speculation(A):
     assert abs(r["demod"].peak - want.audio_peak) < 1e-5
     # the same capture inside a padded buffer (readable slack behind it; a lead-in of zeros is supported but not
     # recommended, see padded_capture_frames): the last outputs come from the matrix-core kernel too
-    z_plain = runner.collect(runner.submit(devs[2]))["z"].clone()
+    z_plain = runner.collect(runner.submit(devs[2], resident=resident))["z"].clone()
     lead, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
     buf = torch.zeros(2 * (lead + n + slack), dtype=torch.int16, device=devs[2].device)
     buf[2 * lead : 2 * (lead + n)] = devs[2]
     buf[2 * (lead + n) :] = 12345  # the slack is read but must never matter
-    r = runner.collect(runner.submit(buf[2 * lead : 2 * (lead + n)], enclosing=buf, lead_frames=lead))
+    torch.cuda.synchronize()
+    r = runner.collect(runner.submit(buf[2 * lead : 2 * (lead + n)], enclosing=buf, lead_frames=lead, resident=resident))
     want = O.run_chain(caps[2], sample_rate=fs, freq_offset=f_off)
     assert r["sign"] == 1 and r["z"].numel() == want.decimated.size
     z_pad = r["z"].cpu().numpy()
