@@ -359,19 +359,38 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 // row (phase p = (J*down) mod up), so the table is read once per `split` part.  A wave owns SIXTEEN CONSECUTIVE
 // output residues (rows p, p+inc, p+2inc, ... with inc = down mod up), one per group of four lanes, which keeps
 // that row's taps in registers (lane `sub` holds taps sub, sub+4, ...).  Per step g the wave produces the 16
-// consecutive outputs J0+16w .. +15 (+ g*up): their input windows overlap, and the cross-lane reduction is two
-// quad steps per output.  The kernel is bound by float64 issue (convert + FMA per tap), so what counts is
-// instructions per output: 16 lanes per output (four butterfly steps for five taps a lane) cost twice as much.
+// consecutive outputs J0+16w .. +15 (+ g*up): their input windows overlap almost entirely (16 outputs x 67 taps
+// touch ~100 inputs), so the wave stages that stretch of the input ONCE in its own 1 KB of LDS (two coalesced loads,
+// prefetched a step ahead, zeros outside [0, n_in)) and every lane picks its taps' samples from there -- per-lane
+// global loads (17 per lane and step) moved 268 B per output through the L1 and were what the kernel waited for.
+// The cross-lane reduction is two quad steps per output.
+// Sum over the four lanes of a quad, in every lane: two DPP quad permutes (register-to-register; __shfl_xor goes
+// through ds_bpermute and its LDS latency, twice in a row, once per output).
+__device__ __forceinline__ double quad_sum(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));  // lanes ^ 2
+    lo = __double2loint(v);
+    hi = __double2hiint(v);
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));  // lanes ^ 1
+    return v;
+}
+
 constexpr int RS_WAVES = 4;
-constexpr int RS_LANES = 4;  // lanes per output
+constexpr int RS_LANES = 4;     // lanes per output
+constexpr int RS_WINDOW = 256;  // floats of LDS per wave: 4*NI taps + the spread of the 16 outputs' positions
+constexpr int RS_SPREAD = 60;   // largest spread of input positions inside a wave that the staged window covers
 
 template <int NI>  // taps per lane = ceil(row_len / 4)
 __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
                                                                int down, int T, long long j0, long long n_out, float *y,
                                                                short *pcm, int split)
 {
-    const int lane = threadIdx.x & 63, sub = lane & (RS_LANES - 1), slot = lane >> 2;
-    const long long wid = static_cast<long long>(blockIdx.x) * RS_WAVES + (threadIdx.x >> 6);
+    static_assert(4 * NI + RS_SPREAD + 4 <= RS_WINDOW, "window too small for this row length");
+    constexpr int CHUNKS = (4 * NI + RS_SPREAD + 63) / 64;  // staging loads per lane and step
+    __shared__ float s_x[RS_WAVES][RS_WINDOW];
+    const int lane = threadIdx.x & 63, sub = lane & (RS_LANES - 1), slot = lane >> 2, wv = threadIdx.x >> 6;
+    const long long wid = static_cast<long long>(blockIdx.x) * RS_WAVES + wv;
     const long long w = wid / split;  // group of 16 residues of (j0 + jj) mod up handled by this wave
     const int part = static_cast<int>(wid - w * split);
     if (w * 16 >= up) return;
@@ -396,28 +415,71 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
 #pragma unroll
     for (int i = 0; i < NI; ++i)
         if (sub + RS_LANES * i >= row_len) h[i] = 0.0;
+    // the wave's window: positions [qmin + g*down + T - (4 NI - 1), qmax + g*down + T]; tap t = sub + 4 i of a lane
+    // reads position q0 + g*down + T - t = window[(q0 - qmin) + 4 NI - 1 - t]
+    long long qmin = ok ? q0 : (1LL << 62), qmax = ok ? q0 : -(1LL << 62);
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+        qmin = min(qmin, __shfl_xor(qmin, m, kWave));
+        qmax = max(qmax, __shfl_xor(qmax, m, kWave));
+    }
+    const bool staged = (qmax - qmin) <= RS_SPREAD;  // wave-uniform; false only where the residues wrap around `up`
+    float *win = s_x[wv];
+    const int my = ok ? static_cast<int>(q0 - qmin) + 4 * NI - 1 - sub : 4 * NI - 1 - sub;
+    const long long w_first = qmin + T - (4 * NI - 1);  // + g*down
+    // staging loads go through a buffer descriptor over x[0, n_in): positions outside it (the stream's edges) come
+    // back as zeros from the range check -- no clamps, no branches around the loads (hipcc waits for a branched load
+    // on the spot, which would undo the prefetch below)
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, static_cast<int>(n_in * 4), 0x00020000);
+    float nxt[CHUNKS];
+    if (staged) {
+        const int k0 = static_cast<int>(w_first + g_lo * down) + lane;
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c)
+            nxt[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (k0 + 64 * c) * 4, 0, 0));
+    }
     for (long long g = g_lo; g < g_hi; ++g) {
         const long long jj = jj0 + g * up;
-        const long long top = q0 + g * down + T - sub;  // input index of this lane's first tap; tap i reads top - 4 i
-        double acc = 0.0;
-        if (top - RS_LANES * (NI - 1) >= 0 && top < n_in) {
-            // interior (almost always): one 64-bit base, immediate offsets, no clamps
-            const float *xp = x + top;
-            float xv[NI];
+        float xv[NI];
+        if (staged) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) xv[i] = xp[-RS_LANES * i];
+            for (int c = 0; c < CHUNKS; ++c)
+                if (lane + 64 * c < RS_WINDOW) win[lane + 64 * c] = nxt[c];
+            {  // next step's stretch: in flight while this one is multiplied (past the last step: harmless, in range or zero)
+                const int k0 = static_cast<int>(w_first + (g + 1) * down) + lane;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) acc = fma(h[i], static_cast<double>(xv[i]), acc);
+                for (int c = 0; c < CHUNKS; ++c)
+                    nxt[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (k0 + 64 * c) * 4, 0, 0));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations complete in order
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xv[i] = win[my - RS_LANES * i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the next step's stores stay behind these reads
         } else {
+            const long long top = q0 + g * down + T - sub;  // input index of this lane's first tap; tap i reads top - 4 i
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const long long nidx = top - RS_LANES * i;
                 const float v = x[min(max(nidx, 0LL), max(n_in - 1, 0LL))];
-                acc = fma(h[i], static_cast<double>((nidx >= 0 && nidx < n_in) ? v : 0.f), acc);
+                xv[i] = (nidx >= 0 && nidx < n_in) ? v : 0.f;
             }
         }
-        acc += __shfl_xor(acc, 2, kWave);
-        acc += __shfl_xor(acc, 1, kWave);  // stays inside the quad
+        // four independent chains: a wave has few neighbours to hide a 17-deep float64 FMA dependency behind
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const double xd = static_cast<double>(xv[i]);
+            if ((i & 3) == 0) a0 = fma(h[i], xd, a0);
+            else if ((i & 3) == 1) a1 = fma(h[i], xd, a1);
+            else if ((i & 3) == 2) a2 = fma(h[i], xd, a2);
+            else a3 = fma(h[i], xd, a3);
+        }
+        double acc = (a0 + a1) + (a2 + a3);
+        acc = quad_sum(acc);
         if (jj < n_out && sub == 0) {
             const float v = static_cast<float>(acc);
             if (y != nullptr) y[jj] = v;
@@ -593,6 +655,7 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     if (n_out == 0) return IQA_OK;
     if (!table_dev || (!y_dev && !pcm16_dev) || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
     if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
+    if (n_in > (1LL << 30) - 4096) return fail_inval("resampler input longer than 2^30 samples: process it in blocks");
     const int64_t g_total = (n_out + up - 1) / up;  // outputs per polyphase row
     // enough waves to fill the chip (>= ~8 per SIMD) while a wave still amortises its 4*NI tap loads over several steps
     const int64_t groups = (static_cast<int64_t>(up) + 15) / 16;

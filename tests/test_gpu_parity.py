@@ -417,6 +417,17 @@ def test_resampler_matches_spec(A):
     np.testing.assert_array_equal(rs.process(D.to_device(x, "float32"), want="pcm16").cpu().numpy(), pcm)
     with pytest.raises(ValueError):
         rs.process(D.to_device(x, "float32"), want="s24")
+    # a later stretch of the output stream through the C ABI (j0 > 0: the residues of one wave wrap around `up`,
+    # the one place where the kernel reads its taps' samples straight from memory instead of the staged window)
+    from ctypes import c_int32, c_int64
+
+    from iq_to_audio_amd import _native as N
+
+    xd, j0, cnt = D.to_device(x, "float32"), 12_345, 9_000
+    part = D.empty(cnt, "float32")
+    N.call("iqa_resample", N.ptr(xd), c_int64(x.size), N.ptr(rs.table_dev), c_int32(rs.plan.up), c_int32(rs.plan.down),
+           c_int32(rs.plan.half_taps), c_int64(j0), c_int64(cnt), N.ptr(part), N.ptr(None), N.stream_ptr())
+    np.testing.assert_array_equal(part.cpu().numpy(), y.cpu().numpy()[j0 : j0 + cnt])
     # C5's rate: gcd(48000, 95969) == 1
     rs5 = Resampler48k(50e6 / 521)
     y5 = rs5.process(D.to_device(x, "float32")).cpu().numpy()
