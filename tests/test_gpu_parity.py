@@ -539,6 +539,117 @@ def test_resident_capture_runner_batch_and_sign_speculation(A, resident):
     assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
 
 
+@pytest.mark.parametrize("fs,fmt", [(10e6, "s16"), (20e6, "s16"), (20e6, "u8")])
+def test_full_size_capture_windows_match_float32_kernel(A, fs, fmt):
+    """BASELINE's full sizes (config 2: 600 M frames = 2.4 GB; config 4's unit: 1.2 G frames = 4.8 GB of int16, 2.4 GB
+    of uint8): the matrix-core channelizer's output over the whole capture against the float32 VALU kernel run on short
+    slices of it (``consumed`` = the slice's position in the capture) -- at the start, around the frames whose byte
+    offsets are 2^31 and 2^32 (address arithmetic), in the middle and at the very end.  A size-independent property:
+    the output at position m depends on frames [m D - L + 1, m D] and on the absolute sample index only."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
+
+    f_off, secs = 25e3, 60.0
+    n = int(round(fs * secs))
+    d, _ = P.choose_decimation(fs, 96_000.0)
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    ntaps = len(taps)
+    unique = O.synth_capture_s16(fs, 0.37, f_off, seed=5)  # 0.37 s: no small period against D or the windows
+    if fmt == "u8":
+        unique = ((unique.astype(np.int32) >> 8) + 128).astype(np.uint8)
+    tile = D.to_device(unique.reshape(-1), "int16" if fmt == "s16" else "uint8")
+    _, slack = ResidentCaptureRunner.padded_capture_frames(d, ntaps)
+    reps = -(-(n + slack) // (tile.numel() // 2))
+    buf = tile.repeat(reps)[: 2 * (n + slack)].contiguous()
+    raw = buf[: 2 * n]
+    ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt=fmt)
+    z = ch.process(raw, last_block=True, halo=(buf, 0))
+    assert ch._kernel.last_kernel == ("k_channelize_mfma_s16_ring" if fmt == "s16" else "k_channelize_mfma_u8_ring")
+    n_out = -(-n // d)
+    assert z.numel() == n_out
+    bytes_per_frame = 4 if fmt == "s16" else 2
+    marks = [0, n // 2, n - 1] + [(1 << e) // bytes_per_frame for e in (31, 32) if (1 << e) // bytes_per_frame < n]
+    span = 1500  # outputs compared per window
+    worst = 0.0
+    for mark in marks:
+        m_mid = min(max(mark // d, 0), n_out - 1)
+        m_lo = max(0, m_mid - span // 2)
+        m_hi = min(n_out, m_lo + span)
+        f_lo = max(0, m_lo * d - (ntaps - 1))           # first frame any compared output depends on
+        f_lo -= f_lo % d                                 # (keeps the slice's decimator phase at 0: simpler indexing)
+        f_hi = min(n, (m_hi - 1) * d + 1)
+        part = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt=fmt)
+        part.consumed = f_lo                             # the slice sits at this position of the capture
+        zs = part.process(raw[2 * f_lo : 2 * f_hi], last_block=True)
+        assert part._kernel.last_kernel == "k_channelize_v1"  # short block: the float32 kernel
+        first = f_lo // d                                # output index of zs[0]
+        # outputs that see the zero history of the slice instead of the capture are skipped (none when f_lo == 0)
+        m0 = m_lo if f_lo == 0 else max(m_lo, -(-(f_lo + ntaps - 1) // d))
+        got, want = z[m0:m_hi], zs[m0 - first : m_hi - first]
+        assert got.numel() == want.numel() and got.numel() >= span // 2
+        err = float((got - want).abs().max())
+        worst = max(worst, err)
+        assert err < (1e-4 if fmt == "s16" else 2e-4), (mark, err)
+    assert worst > 0.0  # (two different kernels: identical output would mean the comparison compared nothing)
+
+
+def test_full_size_chain_windows(A):
+    """BASELINE config 2 at full size through the batch path (600 M frames -> 5.77 M channel-rate samples -> 2.88 M
+    samples at 48 kHz): the demodulator and the resampler at the start, across a reference-chunk boundary, in the middle
+    and at the end of the stream against the same stages run on short slices with fresh state (the de-emphasis filter
+    forgets its state within ~1000 samples; a 48 kHz output depends on 67 inputs), plus the whole-stream invariants:
+    sample counts, per-chunk levels, peak."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
+    from iq_to_audio_amd.processing import ChannelDemod, Resampler48k
+
+    fs, f_off, secs = 10e6, 25e3, 60.0
+    n = int(round(fs * secs))
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    chunk = P.tune_chunk_size(fs, 1_048_576)
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    unique = O.synth_capture_s16(fs, 0.37, f_off, seed=6)
+    tile = D.to_device(unique.reshape(-1), "int16")
+    _, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    buf = tile.repeat(-(-(n + slack) // (tile.numel() // 2)))[: 2 * (n + slack)].contiguous()
+    torch.cuda.synchronize()
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
+                                   n_frames=n, demod_mode="nfm")
+    r = runner.collect(runner.submit(buf[: 2 * n], enclosing=buf, lead_frames=0, resident=True))
+    z, audio = r["z"], r["audio"]
+    n_dec = -(-n // d)
+    assert r["sign"] == 1 and z.numel() == audio.numel() == n_dec == 5_769_231
+    pcm = torch.from_numpy(r["pcm_host"].numpy().copy())
+    assert pcm.numel() == runner.n48 == 2_879_996
+    starts = runner.starts
+    assert len(starts) == 144 and len(r["demod"].chunk_rms_dbfs()) == 144
+    assert abs(float(audio.abs().max()) - min(r["demod"].peak, 0.99)) < 1e-6
+    settle, span = 4000, 3000
+    for mid in (0, int(starts[71]), n_dec // 2 + 777, n_dec):  # start, a chunk boundary, middle, end
+        lo = max(0, min(mid - span // 2, n_dec - span))
+        s0 = max(0, lo - settle)
+        dem = ChannelDemod("nfm", fs_ch, deemph_us=300.0, agc_enabled=True)
+        part = D.empty(lo + span - s0, "float32")
+        dem.process(z[s0 : lo + span], np.array([0], dtype=np.int64), part)
+        err = float((part[lo - s0 :] - audio[lo : lo + span]).abs().max())
+        assert err < 2e-6, (mid, err)  # float64 scans combined in a different order, float32 outputs
+    rs = Resampler48k(fs_ch)
+    up, down = rs.plan.up, rs.plan.down
+    for mid48 in (0, runner.n48 // 2, runner.n48):
+        k = max(0, min(mid48 // up - 1, (n_dec - 2 * down) // down))  # slice starts at input index k * down
+        s, j0 = k * down, k * up
+        cnt = min(2 * up, runner.n48 - j0)
+        y = rs.process(audio[s:], want="pcm16")[:cnt]
+        edge = 40 if s > 0 else 0  # outputs whose 67-sample window reaches in front of the slice
+        assert torch.equal(y[edge:].cpu(), pcm[j0 + edge : j0 + cnt]), mid48
+
+
 @pytest.mark.parametrize("mode,agc,fs,bw", [("am", True, 10e6, 10_000.0), ("usb", False, 20e6, 2_800.0), ("nfm", True, 5e6, 12_500.0)])
 def test_resident_capture_runner_other_modes_and_rates(A, mode, agc, fs, bw):
     """The batch path for the other demodulators and capture shapes: AM at the C2 rate, USB (AGC off: the AGC case is
