@@ -196,6 +196,8 @@ def main() -> None:
         if rec.get("workload_frames") == n_total and kernel_name[0] in (rec.get("kernel") or ""):
             traffic = rec.get("hbm_bytes_per_launch")
 
+    label = ("BASELINE config 2" if (fs, args.seconds) == (10e6, 60.0) else
+             "BASELINE config 4, one GPU's capture" if (fs, args.seconds) == (20e6, 60.0) else "non-BASELINE shape")
     out = {
         "metric": "complex IQ MS/s end-to-end (ingest->48 kHz audio)",
         "value": round(value, 1),
@@ -210,7 +212,7 @@ def main() -> None:
         "dtype": "i8",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE config 2: synthetic {args.seconds:g} s @ {fs/1e6:g} MS/s int16 I/Q, 1 NFM channel, "
+            "workload": f"{label}: synthetic {args.seconds:g} s @ {fs/1e6:g} MS/s int16 I/Q, 1 NFM channel, "
                         f"+25 kHz, bw 12.5 kHz, D={d}, {len(taps)} taps, chunk {chunk}",
             "frames_per_gpu": n_total,
             "parallelism": f"{world} independent capture(s), one per GPU; RCCL gather of 48 kHz audio only",
