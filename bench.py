@@ -80,7 +80,14 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL's kernels on a high-priority stream: the audio gather shares the GPU with a channelizer that holds
+        # every CU for half a millisecond at a time
+        opts = None
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:  # pragma: no cover - older builds
+            opts = None
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
     fs, f_off, bw = float(args.sample_rate), 25e3, 12_500.0
     n_total = int(round(fs * args.seconds))
