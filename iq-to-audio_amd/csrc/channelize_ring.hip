@@ -27,6 +27,11 @@
 // Every other decimation (odd D, D > 256 in several k-step ranges) uses row-staged slots, see RingGeo.
 #include "mfma_common.h"
 
+// cache-policy bits of the LDS-DMA loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); a build-time knob for experiments
+#ifndef IQA_RING_DMA_AUX
+#define IQA_RING_DMA_AUX 0
+#endif
+
 #include <cmath>
 #include <type_traits>
 
@@ -189,12 +194,12 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
             if (c.lane < (G::KBYTES / 16) * KS) {
 #pragma unroll
                 for (int j = 0; j < 32; ++j)
-                    __builtin_amdgcn_global_load_lds(src + j * row_bytes, (ring_lds_t *)(dst + j * G::PITCH), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(src + j * row_bytes, (ring_lds_t *)(dst + j * G::PITCH), 16, 0, IQA_RING_DMA_AUX);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 2 * KS; ++i)
-                __builtin_amdgcn_global_load_lds(src + i * 1024, (ring_lds_t *)(dst + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src + i * 1024, (ring_lds_t *)(dst + i * 1024), 16, 0, IQA_RING_DMA_AUX);
         }
     };
     if (STREAM) {
@@ -248,7 +253,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     auto issue = [&](int tile, int slot, int i) {
         const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes + i * 2048;
         char *dst = c.smem + (slot * 2 + cp) * SLOT + (rt & 1) * 1024 + i * 2048;
-        __builtin_amdgcn_global_load_lds(src, (ring_lds_t *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, (ring_lds_t *)dst, 16, 0, IQA_RING_DMA_AUX);
     };
     if (STREAM) {
 #pragma unroll
