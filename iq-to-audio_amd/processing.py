@@ -21,7 +21,7 @@ import logging
 import math
 import threading
 from collections import OrderedDict
-from ctypes import byref, c_double, c_int32, c_int64, c_void_p
+from ctypes import byref, c_double, c_int32, c_int64
 from dataclasses import dataclass
 from pathlib import Path
 
