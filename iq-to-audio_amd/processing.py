@@ -223,13 +223,16 @@ class _ChannelKernel:
         lds = 160 * 1024 - k_count * P.MFMA_KSTEP_BYTES - self._VARIANT[variant][1]
         return int(min(6144, (lds // 16 - 160) // 32 * 32))
 
-    @staticmethod
-    def _block_outputs(n_out: int, rmax: int) -> int:
+    #: workgroups of a capture-long launch: one per CU of the MI355X
+    launch_blocks = 256
+
+    @classmethod
+    def _block_outputs(cls, n_out: int, rmax: int) -> int:
         """Outputs per block for a launch of ``n_out`` outputs: as large as LDS allows, but chosen so that the
         number of blocks is a multiple of the 256 CUs (one block per CU, no ragged last round).  The ring kernel
         has no LDS bound (``rmax`` huge): every CU gets ONE contiguous range of the launch."""
-        rounds = max(1, -(-n_out // (256 * rmax)))
-        per = -(-n_out // (256 * rounds))
+        rounds = max(1, -(-n_out // (cls.launch_blocks * rmax)))
+        per = -(-n_out // (cls.launch_blocks * rounds))
         return int(min(rmax, max(512, -(-per // 32) * 32)))
 
     def _valu(self, raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev):

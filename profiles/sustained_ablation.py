@@ -21,6 +21,7 @@ raw = torch.from_numpy(host).to("cuda").repeat(60)[: 2 * n_total].contiguous()
 taps = A.design_channel_filter(fs, bw, d)
 z = D.empty(-(-n_total // d), "complex64")
 PR._ChannelKernel.mfma_variant = "ring"
+PR._ChannelKernel.launch_blocks = int(os.environ.get("RING_BLOCKS", "256"))  # fewer than 256: some CUs stay free
 
 def smi():
     try:
