@@ -214,7 +214,8 @@ def main() -> None:
         if rec.get("workload_frames") == n_total and kernel_name[0] in (rec.get("kernel") or ""):
             traffic = rec.get("hbm_bytes_per_launch")
 
-    label = ("BASELINE config 2" if (fs, args.seconds) == (10e6, 60.0) else
+    label = ("BASELINE config 1 (the reference's --benchmark capture)" if (fs, args.seconds) == (2.5e6, 5.0) else
+             "BASELINE config 2" if (fs, args.seconds) == (10e6, 60.0) else
              "BASELINE config 4, one GPU's capture" if (fs, args.seconds) == (20e6, 60.0) else "non-BASELINE shape")
     out = {
         "metric": "complex IQ MS/s end-to-end (ingest->48 kHz audio)",
