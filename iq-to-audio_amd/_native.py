@@ -147,12 +147,20 @@ def call(name: str, *args) -> None:
     raise RuntimeError(f"{name}: {msg}")
 
 
+_torch_with_gpu = None
+
+
 def require_gpu():
-    """Device 0..N-1 visible through torch; raises RuntimeError otherwise (no fallback)."""
+    """Device 0..N-1 visible through torch; raises RuntimeError otherwise (no fallback).  The positive answer is
+    remembered: ``torch.cuda.is_available()`` costs ~8 us and this is called from every helper."""
+    global _torch_with_gpu
+    if _torch_with_gpu is not None:
+        return _torch_with_gpu
     import torch
 
     if not torch.cuda.is_available():
         raise RuntimeError("no MI355X visible to this process: the HIP hot path has no CPU fallback")
+    _torch_with_gpu = torch
     return torch
 
 
@@ -164,6 +172,11 @@ def ptr(t) -> c_void_p:
 
 
 def stream_ptr() -> c_void_p:
+    """The current torch stream of the current device as a raw ``hipStream_t`` (the direct binding: building a
+    ``torch.cuda.Stream`` object for every native call costs more than some of the launches)."""
     import torch
 
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return c_void_p(raw(torch._C._cuda_getDevice()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)

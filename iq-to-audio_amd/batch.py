@@ -14,7 +14,7 @@ import numpy as np
 from . import _dev as D
 from . import _native as N
 from . import dsp_plan as P
-from .processing import ChannelDemod, Channelizer, MixSignProbe, Resampler48k
+from .processing import ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps
 
 
 class ResidentCaptureRunner:
@@ -44,7 +44,7 @@ class ResidentCaptureRunner:
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
                  fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None):
         torch = D.torch_mod()
-        self.taps, self.fs, self.f_off, self.d, self.fs_ch = np.asarray(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
+        self.taps, self.fs, self.f_off, self.d, self.fs_ch = immutable_taps(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
         self.chunk, self.n_frames, self.fmt, self.iq_order = int(chunk), int(n_frames), fmt, iq_order
         self.demod_args = dict(mode=demod_mode, deemph_us=deemph_us, agc_enabled=agc_enabled)
         self.override = mix_sign_override if mix_sign_override in (1, -1) else None

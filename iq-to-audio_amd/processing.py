@@ -339,17 +339,45 @@ _KERNEL_CACHE_MAX = 16
 _KERNEL_CACHE_LOCK = threading.Lock()
 
 
+_TAPS_MEMO: dict = {}  # id(array) -> (array, its bytes, their hash), for arrays that cannot change
+
+
+def _taps_fingerprint(taps: np.ndarray):
+    """(bytes, hash) of a tap vector.  Hashing 50-260 KB costs 25-130 us, and a batch asks three times per capture with
+    the same array: an array that owns its data and is not writeable (``immutable_taps``) is fingerprinted once."""
+    frozen = (not taps.flags.writeable) and taps.base is None
+    if frozen:
+        memo = _TAPS_MEMO.get(id(taps))
+        if memo is not None and memo[0] is taps:
+            return memo[1], memo[2]
+    raw = taps.tobytes()
+    h = hash(raw)
+    if frozen:
+        with _KERNEL_CACHE_LOCK:
+            if len(_TAPS_MEMO) >= 64:
+                _TAPS_MEMO.clear()
+            _TAPS_MEMO[id(taps)] = (taps, raw, h)
+    return raw, h
+
+
+def immutable_taps(taps) -> np.ndarray:
+    """A private, contiguous, read-only copy of a tap vector (what the kernel cache can recognise without hashing)."""
+    out = np.array(taps, copy=True, order="C")
+    out.setflags(write=False)
+    return out
+
+
 def _cached_kernel(taps: np.ndarray, *, sample_rate: float, freq_offset: float, mix_sign: int, decimation: int,
                    fmt: str, iq_order: str):
     """(plan, kernel) for this configuration, planned once per process and device."""
     taps = np.ascontiguousarray(taps)
-    raw = taps.tobytes()
-    key = (hash(raw), taps.dtype.str, taps.shape, float(sample_rate), float(freq_offset), int(mix_sign), int(decimation),
+    raw, raw_hash = _taps_fingerprint(taps)
+    key = (raw_hash, taps.dtype.str, taps.shape, float(sample_rate), float(freq_offset), int(mix_sign), int(decimation),
            fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, _ChannelKernel.ring_acc32,
            D.torch_mod().cuda.current_device())
     with _KERNEL_CACHE_LOCK:
         hit = _KERNEL_CACHE.get(key)
-        if hit is not None and hit[0] == raw:
+        if hit is not None and (hit[0] is raw or hit[0] == raw):
             _KERNEL_CACHE.move_to_end(key)
             return hit[1], hit[2]
     lpad = int(N.lib().iqa_taps_padded_len(len(taps)))

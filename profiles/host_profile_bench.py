@@ -3,7 +3,7 @@ GPU work negligible, so ms_per_step ~ host time per step."""
 import cProfile, pstats, sys, io
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.argv = ["bench.py", "--steps", "200", "--warmup", "5", "--no-cpu-baseline", "--seconds", "2", "--unique-seconds", "1"]
+sys.argv = ["bench.py", "--steps", "400", "--warmup", "20", "--no-cpu-baseline", "--sample-rate", "2.5e6", "--seconds", "5"]
 import bench
 pr = cProfile.Profile()
 pr.enable()
