@@ -65,6 +65,7 @@ def main() -> None:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (see iq_to_audio_amd/__init__.py; before the runtime initialises)
     import torch
     import torch.distributed as dist
 
@@ -134,20 +135,32 @@ def main() -> None:
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + n_untimed)]
     tickets = []
 
+    lag = []  # the capture whose audio has not been handed to the gather yet
+
+    def queue_gather(t, after):
+        runner.egress.wait_event(after)  # t's PCM16 is complete
+        with torch.cuda.stream(runner.egress):  # the gather overlaps the next captures' kernels
+            while pending:
+                pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
+            t["pcm"].record_stream(runner.egress)
+            pending.append(dist.gather(t["pcm"].view(torch.uint8), gathered, dst=0, async_op=True))
+
     def step(i: int):
         # resident: the capture was complete in HBM before the timed region (the metric's premise)
         t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]), enclosing=buf, lead_frames=lead, resident=True)
         tickets.append(t)
         if distributed:
-            runner.egress.wait_event(runner.tail_event(t))  # this capture's PCM16 is complete
-            with torch.cuda.stream(runner.egress):    # the gather overlaps the next capture's kernels
-                while pending:
-                    pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
-                t["pcm"].record_stream(runner.egress)
-                pending.append(dist.gather(t["pcm"].view(torch.uint8), gathered, dst=0, async_op=True))
+            # the PREVIOUS capture's audio goes to the gather now: this capture's first timing event lies behind its
+            # last kernel, so no event of its own is needed (an event record costs the compute stream ~7 us)
+            if lag:
+                queue_gather(lag.pop(), ev_k0[i])
+            lag.append(t)
         return t
 
     def fence():
+        if lag:  # the last capture's audio
+            t = lag.pop()
+            queue_gather(t, runner.tail_event(t))
         for t in tickets:
             runner.collect(t)
         del tickets[:]
@@ -175,8 +188,8 @@ def main() -> None:
     for i in range(args.steps):
         last = step(n_untimed + i)
         marks.append(time.perf_counter() - t0)
+    fence()  # (queues the last capture's gather before its buffers go back to the runner)
     res = runner.collect(last)
-    fence()
     sign, audio, kernel_name = res["sign"], res["audio"], [res["kernel"]]
     if os.environ.get("IQA_BENCH_DEBUG"):
         stats1 = torch.cuda.memory_stats()

@@ -11,6 +11,15 @@ from __future__ import annotations
 
 __version__ = "0.1.0"
 
+import os as _os
+
+# The batch path keeps three streams beside the caller's (egress, aux, and RCCL's own in a multi-GPU job).  The HIP
+# runtime maps streams onto four hardware queues by default, so a fifth stream shares a queue with another one -- measured
+# with RCCL in the process: the aux stream landed on the compute stream's queue, its launches ran after the resampler
+# instead of beside it, +4.5 % per capture.  Read by the runtime when it initialises (the first HIP call), so setting
+# it here works unless the application has already used the GPU; an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import _native as native  # noqa: F401
 from .decoders import Decoder, DecoderStats, create_decoder  # noqa: F401
 from .processing import (  # noqa: F401

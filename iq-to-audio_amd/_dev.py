@@ -11,6 +11,33 @@ def torch_mod():
     return N.require_gpu()
 
 
+class on_stream:
+    """``with on_stream(s, back):`` -- make ``s`` the current torch stream and ``back`` afterwards.  For callers that
+    know which stream is current (``torch.cuda.stream`` looks it up first, ~10 us per block on this host)."""
+
+    __slots__ = ("stream", "back")
+
+    def __init__(self, stream, back):
+        self.stream, self.back = stream, back
+
+    def __enter__(self):
+        torch_mod().cuda.set_stream(self.stream)
+        return self.stream
+
+    def __exit__(self, *exc):
+        torch_mod().cuda.set_stream(self.back)
+        return False
+
+
+def current_raw_stream() -> int:
+    """``hipStream_t`` of the current torch stream, as an integer."""
+    torch = torch_mod()
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return int(raw(torch._C._cuda_getDevice()))
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
 def device(index: int | None = None):
     torch = torch_mod()
     return torch.device("cuda", torch.cuda.current_device() if index is None else index)

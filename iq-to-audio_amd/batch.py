@@ -55,6 +55,7 @@ class ResidentCaptureRunner:
         # One compute stream.  A second one for demod/resample beside the next channelizer was measured and dropped
         # (-6 % per capture at best while stretching the channelizer by 40 %: the small kernels take its CU slots).
         self.compute = torch.cuda.current_stream()
+        self._compute_raw = int(self.compute.cuda_stream)
         self.egress = torch.cuda.Stream()
         self.aux = torch.cuda.Stream()
         self._ring_done = None  # event behind the most recent channelizer launch (the aux stream starts from there)
@@ -73,7 +74,7 @@ class ResidentCaptureRunner:
         warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
         # record_done=False: the events that lie behind the probes are the capture's own (set in _chain) -- an event
         # record between two kernels of a stream costs ~7 us on this part
-        with torch.cuda.stream(self.aux if resident else self.compute):
+        with D.on_stream(self.aux if resident else self.compute, self.compute):
             return MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order,
                                 record_done=False)
 
@@ -85,7 +86,7 @@ class ResidentCaptureRunner:
         chan.plan_ahead()
         dem = slot["dem"]
         side = self.aux if resident else None
-        with torch.cuda.stream(self.aux if resident else self.compute):
+        with D.on_stream(self.aux if resident else self.compute, self.compute):
             dem.reset()
         dem.prepare(self.n_dec, self.starts)
         # gate: compute stream, behind this capture's probes (if they are there), in front of its channelizer -- the
@@ -93,12 +94,12 @@ class ResidentCaptureRunner:
         gate = None
         if events is None:
             gate = torch.cuda.Event()
-            gate.record()
+            gate.record(self.compute)
         prev = self._egress_pending
         chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo, edge_stream=side)
         if events is None:
             ring_done = torch.cuda.Event()
-            ring_done.record()
+            ring_done.record(self.compute)
         else:
             gate, ring_done = events[0], events[1]
         self._ring_done = ring_done
@@ -142,12 +143,13 @@ class ResidentCaptureRunner:
             self.egress.wait_event(gate)  # (behind the capture's last kernel too: same stream, recorded later)
         else:
             self.egress.wait_event(self.tail_event(t))
-        with torch.cuda.stream(self.egress):
+        # (called with the compute stream current: from submit/_chain and from collect)
+        with D.on_stream(self.egress, self.compute):
             t["pcm"].record_stream(self.egress)
             host = t["slot"]["pcm_host"]
             N.call("iqa_trickle_copy", N.ptr(t["pcm"]), c_void_p(host.data_ptr()), c_int64(host.numel() * host.element_size()),
                    c_int32(self.egress_workgroups), N.stream_ptr())
-            t["done"].record()
+            t["done"].record(self.egress)
         t["egress_queued"] = True
         self._egress_pending = None
 
@@ -170,7 +172,7 @@ class ResidentCaptureRunner:
         depend on nothing else may run on the aux stream, ahead of the compute stream.  ``events``: optional pair of
         torch events recorded directly in front of / behind the channelizer's dominant launch."""
         torch = D.torch_mod()
-        if torch.cuda.current_stream() != self.compute:
+        if D.current_raw_stream() != self._compute_raw:
             raise RuntimeError("submit() must be called with the stream the runner was created on as the current stream")
         slot = self.slots[self._next % self.SLOTS]
         self._next += 1
@@ -195,6 +197,8 @@ class ResidentCaptureRunner:
         slot = ticket["slot"]
         if ticket.get("collected"):
             return ticket["result"]
+        if D.current_raw_stream() != self._compute_raw:  # (it may queue the D2H, or the whole capture again)
+            raise RuntimeError("collect() must be called with the stream the runner was created on as the current stream")
         sign = ticket["sign"]
         if self._egress_pending is ticket:
             self._flush_egress()
