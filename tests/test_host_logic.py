@@ -376,3 +376,26 @@ def test_mfma_interior_with_lead_in_and_slack():
     assert (m_a3 - 64) * d + 1 >= 1_000_000
     # three tap-row groups (32769 taps at D = 208): the read range starts 192 rows back
     assert P.mfma_interior(0, 10_000_000, 0, 48_077, 208, 13, 3)[0] == 192
+
+
+def test_taps_fingerprint_and_runtime_defaults():
+    """Host-side plumbing of the batch path: a read-only, owning tap vector is fingerprinted once (the kernel cache is
+    asked three times per capture), a writable one every time (it may have changed); importing the package asks the HIP
+    runtime for eight hardware queues unless the application chose a number itself."""
+    import os
+
+    import iq_to_audio_amd  # noqa: F401
+    from iq_to_audio_amd import processing as PR
+
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
+    taps = np.linspace(-1.0, 1.0, 4097)
+    frozen = PR.immutable_taps(taps)
+    assert not frozen.flags.writeable and frozen.base is None and np.array_equal(frozen, taps)
+    a, b = PR._taps_fingerprint(frozen), PR._taps_fingerprint(frozen)
+    assert a[0] is b[0] and a[1] == b[1] == hash(taps.tobytes())
+    w1 = PR._taps_fingerprint(taps)
+    taps[7] = 123.0
+    w2 = PR._taps_fingerprint(taps)
+    assert w1[0] is not w2[0] and w1[0] != w2[0]
+    view = frozen[:100]  # a read-only VIEW is not trusted (its base could change hands)
+    assert PR._taps_fingerprint(view)[0] is not PR._taps_fingerprint(view)[0]
