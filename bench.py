@@ -90,6 +90,15 @@ def main() -> None:
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL's send/recv kernel needs 19.7 KB of LDS and ~280 VGPRs per workgroup (librccl's gfx950 code object): it
+        # cannot share a CU with a channelizer workgroup (149 KB of LDS at D = 104), and a channelizer launch that wants
+        # all 256 CUs waits for every CU a gather still sits on.  So with a gather in the job the capture-long launches
+        # use 240 workgroups (measured cost at N = 1: 1.5 %, the clock gives most of it back) and the gather -- 5.76 MB
+        # per peer and capture, nowhere near needing more -- is kept to 8 channels = 8 workgroups.
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
+        from iq_to_audio_amd import processing as _PR
+
+        _PR._ChannelKernel.launch_blocks = int(os.environ.get("IQA_BENCH_RING_BLOCKS", "240"))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL's kernels on a high-priority stream: the audio gather shares the GPU with a channelizer that holds
