@@ -22,6 +22,7 @@ taps = A.design_channel_filter(fs, bw, d)
 z = D.empty(-(-n_total // d), "complex64")
 PR._ChannelKernel.mfma_variant = "ring"
 PR._ChannelKernel.launch_blocks = int(os.environ.get("RING_BLOCKS", "256"))  # fewer than 256: some CUs stay free
+PR._ChannelKernel.ring_acc32 = os.environ.get("ACC32", "1") == "1"  # 0: int64 sums, 16-bit taps (no ablation builds: DBGS=0)
 
 def smi():
     try:
