@@ -25,11 +25,11 @@ for off, mode, bw in targets:
     runners.append((mode, len(taps), ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=off, decimation=d, fs_channel=fs_ch, chunk=chunk,
                                                           n_frames=n_total, demod_mode=mode, agc_enabled=True)))
 def one_pass():
-    ts = [r.submit(raw, enclosing=buf, lead_frames=0) for _, _, r in runners]
+    ts = [r.submit(raw, enclosing=buf, lead_frames=0, resident=True) for _, _, r in runners]
     return [r.collect(t) for (_, _, r), t in zip(runners, ts)]
-for _ in range(2): res = one_pass()
+for _ in range(int(__import__("os").environ.get("WARM", "10"))): res = one_pass()
 torch.cuda.synchronize()
-K = 5
+K = int(__import__("os").environ.get("K", "60"))
 t0 = time.perf_counter()
 for _ in range(K): res = one_pass()
 torch.cuda.synchronize()
