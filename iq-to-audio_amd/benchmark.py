@@ -39,33 +39,47 @@ def _generate_synthetic_iq(path: Path, sample_rate: float, seconds: float, freq_
 
 def run_benchmark(*, seconds: float, sample_rate: float, freq_offset: float, center_freq: float | None,
                   target_freq: float | None, base_kwargs: Mapping[str, object] | None) -> int:
-    """Same contract as the reference's ``run_benchmark`` (benchmark.py:41-127): returns 0 on success
-    and logs "Benchmark processed N IQ samples in T s (Rx realtime)"."""
+    """Same contract as the reference's ``run_benchmark`` (benchmark.py:41-127): returns 0 on success and logs
+    "Benchmark processed N IQ samples in T s (Rx realtime)".
+
+    Where the synthetic tone sits (benchmark.py:61-72): when BOTH ``center_freq`` and ``target_freq`` are given the
+    tone is generated at ``target_freq - center_freq`` and ``freq_offset`` is only range-checked; with one of them
+    the other is derived from ``freq_offset``; with neither the centre is 400 MHz.  Either way the pipeline is tuned
+    onto the tone."""
     if seconds <= 0:
         raise ValueError("Benchmark duration must be positive.")
     if sample_rate <= 0:
         raise ValueError("Benchmark sample rate must be positive.")
     if abs(freq_offset) >= sample_rate / 2.0:
         raise ValueError("Benchmark offset must be within half the sample rate.")
-    if center_freq is None:
-        center_freq = 400_000_000.0 if target_freq is None else target_freq - freq_offset
-    if target_freq is None:
+    tone_offset = freq_offset
+    if center_freq is not None and target_freq is not None:
+        tone_offset = target_freq - center_freq
+    elif center_freq is not None:
         target_freq = center_freq + freq_offset
-    kwargs = dict(base_kwargs or {})
-    for k in ("in_path", "target_freq", "center_freq", "output_path"):
-        kwargs.pop(k, None)
+    elif target_freq is not None:
+        center_freq = target_freq - freq_offset
+    else:
+        center_freq = 400_000_000.0
+        target_freq = center_freq + freq_offset
+    settings = dict(base_kwargs or {})
+    mode = settings.get("demod_mode")
+    mode = mode.lower() if isinstance(mode, str) else "nfm"
+    LOG.info("Running benchmark: %.2f s at %.2f MS/s, demod=%s, offset %.1f kHz", seconds, sample_rate / 1e6,
+             mode.upper(), tone_offset / 1e3)
     with tempfile.TemporaryDirectory(prefix="iq_bench_") as tmp:
-        wav = Path(tmp) / "synthetic_iq.wav"
-        out = Path(tmp) / "benchmark_audio.wav"
-        _generate_synthetic_iq(wav, sample_rate, seconds, freq_offset)
-        config = ProcessingConfig(in_path=wav, target_freq=float(target_freq), center_freq=float(center_freq),
-                                  output_path=out, **kwargs)
+        wav = Path(tmp) / f"benchmark_fc-{int(center_freq)}Hz.wav"
+        _generate_synthetic_iq(wav, sample_rate, seconds, tone_offset)
+        settings.update(target_freq=float(target_freq), center_freq=float(center_freq), center_freq_source="benchmark",
+                        demod_mode=mode, output_path=Path(tmp) / f"benchmark_audio_{mode}.wav", probe_only=False)
+        settings.pop("in_path", None)
         t0 = time.perf_counter()
-        ProcessingPipeline(config).run(progress_sink=None)
+        result = ProcessingPipeline(ProcessingConfig(in_path=wav, **settings)).run(progress_sink=None)
         elapsed = time.perf_counter() - t0
-    n = int(round(sample_rate * seconds))
-    LOG.info("Benchmark processed %d IQ samples in %.3f s (%.2fx realtime).", n, elapsed,
+    LOG.info("Benchmark processed %.0f IQ samples in %.3f s (%.2fx realtime).", sample_rate * seconds, elapsed,
              seconds / elapsed if elapsed > 0 else float("inf"))
+    LOG.info("Channel decimation %d -> %.1f Hz; audio peak %.2f dBFS.", result.decimation, result.fs_channel,
+             20.0 * math.log10(max(result.audio_peak, 1e-6)))
     return 0
 
 

@@ -190,6 +190,32 @@ def write_wav_iq(path: Path, frames: np.ndarray, sample_rate: int, fmt: str = "s
         fh.write(data)
 
 
+def encode_iq_slice(z: np.ndarray, codec: str, container: str = "raw") -> np.ndarray:
+    """Interleaved I,Q values of a decimated slice in the INPUT's sample format (pass-through ``--demod none``).
+
+    Headerless outputs follow the reference's own quantisers (processing.py:527-539): ``pcm_s16le`` = the value
+    limited to [-1, 0.999969], times 32767, truncated toward zero; ``pcm_u8`` = the value limited to [-1, 1], mapped
+    to (x + 1) * 127.5 and rounded half-to-even; ``pcm_f32le`` unchanged.
+    WAV outputs go through libsndfile in the reference (``SoundFile.write`` of float32 frames, processing.py:557-584):
+    third-party and absent here -- **parity unpinned**; restated from libsndfile's float->PCM rule with
+    normalisation on: PCM_16 = rint(x * 32767), PCM_U8 = rint(x * 127) + 128 (saturated here; libsndfile wraps
+    unless clipping is switched on), FLOAT unchanged.
+    """
+    pairs = np.ascontiguousarray(z, dtype=np.complex64).view(np.float32)  # I0, Q0, I1, Q1, ... as they lie in memory
+    if codec == "pcm_f32le":
+        return pairs.astype("<f4", copy=False)
+    if codec not in ("pcm_s16le", "pcm_u8"):
+        raise ValueError(f"Unsupported raw codec {codec}")
+    if container == "wav":
+        if codec == "pcm_s16le":
+            return np.clip(np.rint(pairs.astype(np.float64) * 32767.0), -32768, 32767).astype("<i2")
+        return np.clip(np.rint(pairs.astype(np.float64) * 127.0) + 128.0, 0, 255).astype(np.uint8)
+    if codec == "pcm_s16le":
+        return (np.minimum(np.maximum(pairs, np.float32(-1.0)), np.float32(0.999969)) * np.float32(32767.0)).astype("<i2")
+    limited = np.minimum(np.maximum(pairs, np.float32(-1.0)), np.float32(1.0))
+    return np.round((limited + np.float32(1.0)) * np.float32(127.5)).astype(np.uint8)
+
+
 def read_wav_pcm16_mono(path: Path) -> tuple[np.ndarray, int]:
     """Read back a mono PCM16 WAV written by :func:`write_wav_pcm16` (tests)."""
     raw = Path(path).read_bytes()

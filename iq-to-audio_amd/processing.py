@@ -809,20 +809,6 @@ class Resampler48k:
         return pcm
 
 
-def _encode_iq_raw(samples: np.ndarray, codec: str) -> bytes:
-    """Pass-through slice encoding (reference processing.py _encode_iq_raw)."""
-    inter = np.empty(samples.size * 2, dtype=np.float32)
-    inter[0::2] = samples.real
-    inter[1::2] = samples.imag
-    if codec == "pcm_f32le":
-        return inter.astype("<f4").tobytes()
-    if codec == "pcm_s16le":
-        return (np.clip(inter, -1.0, 0.999969) * 32767.0).astype("<i2").tobytes()
-    if codec == "pcm_u8":
-        return np.round((np.clip(inter, -1.0, 1.0) + 1.0) * 127.5).astype(np.uint8).tobytes()
-    raise ValueError(f"Unsupported codec {codec}")
-
-
 class _BlockStager:
     """Capture blocks: memory-mapped file -> one of two pinned host buffers (filled by a helper thread,
     overlapping the previous block's GPU work) -> device tensor by asynchronous H2D copy.
@@ -1003,12 +989,11 @@ class _Target:
         if self.pass_through:
             zs = self.z_all[: self.pos_dec].cpu().numpy()
             self.peak = float(np.max(np.abs(zs))) if zs.size else 0.0
-            payload = _encode_iq_raw(zs, info.codec)
+            values = iqio.encode_iq_slice(zs, info.codec, info.container)
             if info.container == "wav":
-                arr = np.frombuffer(payload, dtype=iqio.NP_DTYPE[info.fmt])
-                iqio.write_wav_iq(self.output_path, arr, int(round(self.fs_channel)), info.fmt)
+                iqio.write_wav_iq(self.output_path, values, max(1, int(round(self.fs_channel))), info.fmt)
             else:
-                self.output_path.write_bytes(payload)
+                self.output_path.write_bytes(values.tobytes())
             return
         self.demod.decoder.finalize()
         audio = self.audio_all[: self.pos_dec]

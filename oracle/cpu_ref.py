@@ -296,6 +296,10 @@ def _seq_lib():
         lib.dc_block_f32.restype = None
         lib.agc_f32.argtypes = [fp, fp, ctypes.c_size_t, ctypes.c_double, ctypes.c_double]
         lib.agc_f32.restype = None
+        lib.dc_block_f64.argtypes = [fp, fp, ctypes.c_size_t, ctypes.c_double, dp, dp]
+        lib.dc_block_f64.restype = None
+        lib.agc_f64.argtypes = [fp, fp, ctypes.c_size_t, ctypes.c_double, ctypes.c_double]
+        lib.agc_f64.restype = None
         _SEQ_LIB = lib
     return _SEQ_LIB
 
@@ -365,6 +369,25 @@ def agc(x: np.ndarray, target: float = AGC_TARGET, decay: float = AGC_DECAY) -> 
     out = np.empty(xin.size, dtype=np.float32)
     fp = ctypes.POINTER(ctypes.c_float)
     _seq_lib().agc_f32(xin.ctypes.data_as(fp), out.ctypes.data_as(fp), xin.size, target, decay)
+    return out
+
+
+def ssb_demod_f64(z: np.ndarray, st: "DcState", *, lsb: bool = False, agc_enabled: bool = True) -> np.ndarray:
+    """decoders/ssb.py:39-61 with both recurrences evaluated in float64 (oracle/seq_f32.c: dc_block_f64, agc_f64).
+    NOT the reference's arithmetic: the comparison target that separates logic from rounding in the SSB+AGC tests.
+    ``st`` carries the DC blocker's state across calls as doubles; the gain restarts at 1.0 every call."""
+    if z.size == 0:
+        return np.empty(0, dtype=np.float32)
+    base = np.ascontiguousarray((np.conj(z) if lsb else z).real, dtype=np.float32)
+    dc = np.empty(base.size, dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    xp, yp = ctypes.c_double(st.x_prev), ctypes.c_double(st.y_prev)
+    _seq_lib().dc_block_f64(base.ctypes.data_as(fp), dc.ctypes.data_as(fp), base.size, st.radius, ctypes.byref(xp), ctypes.byref(yp))
+    st.x_prev, st.y_prev = float(xp.value), float(yp.value)
+    if not agc_enabled:
+        return dc
+    out = np.empty(dc.size, dtype=np.float32)
+    _seq_lib().agc_f64(dc.ctypes.data_as(fp), out.ctypes.data_as(fp), dc.size, AGC_TARGET, AGC_DECAY)
     return out
 
 

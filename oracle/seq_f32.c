@@ -82,3 +82,40 @@ void agc_f32(const float *x, float *y, size_t n, double target, double decay)
         y[i] = s * gain;
     }
 }
+
+/*
+ * The same two recurrences in float64 -- NOT the reference's arithmetic.  Used by the SSB+AGC parity tests to
+ * separate LOGIC (which sample restarts the gain, which samples pass the 1e-6 threshold, how the DC blocker's state
+ * crosses block edges: must agree with the GPU to ~1e-6) from ROUNDING (float32 sequential in the reference, float64
+ * scans on the GPU: amplified by the AGC's 1/|s|, see tests/test_gpu_configs.py::ssb_agc_evidence).
+ * Interfaces mirror the float32 functions: float32 samples in and out, the DC-blocked sample is rounded to float32
+ * before the AGC sees it (as both implementations store it), the threshold test is the float32 one.
+ */
+void dc_block_f64(const float *x, float *y, size_t n, double r, double *x_prev_io, double *y_prev_io)
+{
+    double xp = *x_prev_io, yp = *y_prev_io;
+    const double rr = (double)(float)r;
+    for (size_t i = 0; i < n; ++i) {
+        const double s = (double)x[i];
+        const double out = s - xp + rr * yp;
+        y[i] = (float)out;
+        xp = s;
+        yp = out;
+    }
+    *x_prev_io = xp;
+    *y_prev_io = yp;
+}
+
+void agc_f64(const float *x, float *y, size_t n, double target, double decay)
+{
+    const double tf = (double)(float)target, df = (double)(float)decay;
+    const float thr = (float)1e-6;
+    double gain = 1.0;
+    for (size_t i = 0; i < n; ++i) {
+        const float s = x[i];
+        const float mag = fabsf(s);
+        if (mag > thr)
+            gain += df * (tf / (double)mag - gain);
+        y[i] = (float)((double)s * gain);
+    }
+}

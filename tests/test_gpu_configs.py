@@ -1,0 +1,318 @@
+"""GPU parity tests for the BASELINE configurations as WORKLOADS (not just their filter shapes):
+
+* config 3 -- 20 MS/s, five simultaneous targets nfm/am/usb/lsb/nfm with bandwidths 12.5k/10k/2.8k/2.8k/12.5k,
+  AGC on -- through :class:`MultiChannelPipeline` against one oracle chain per target;
+* config 5's per-GPU unit -- 50 MS/s, D = 521, five NFM channels with de-emphasis out of a 40-carrier capture --
+  through channelizer + demodulator + 48 kHz resampler against the oracle;
+* SSB with AGC on, where the reference itself is ill-conditioned: the error is localised BY CAUSE instead of being
+  bounded loosely (see :func:`ssb_agc_evidence`).
+
+Bars (BASELINE.json north_star): sample counts exact; float audio within 1e-4 RMS.  Asserted tolerances are stated
+per test.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import iq_to_audio_amd as pkg
+
+    pkg.native.lib()  # fail loudly if the HIP library is missing
+    pkg.native.require_gpu()
+    return pkg
+
+
+def rms(a):
+    a = np.asarray(a)
+    return float(np.sqrt(np.mean(np.abs(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)) ** 2)))
+
+
+# ---- SSB + AGC: where the error lives -------------------------------------------------------------
+
+
+def oracle_demod_chunks(z, chunk_lens, mode, fs_ch, agc=True, clip=True):
+    """The oracle's decoder + writer clip over the given per-chunk lengths (AGC gain restarts per chunk,
+    reference decoders/ssb.py:72; DC-blocker state carried, decoders/common.py:28-29)."""
+    st = O.DemodState(mode, fs_ch, agc_enabled=agc)
+    out, pos = [], 0
+    for n in chunk_lens:
+        y, _ = O.demodulate(z[pos : pos + n], st)
+        out.append(np.clip(y, -0.99, 0.99) if clip else y)
+        pos += int(n)
+    return np.concatenate(out) if out else np.empty(0, np.float32)
+
+
+def agc_sensitivity(z, chunk_lens, mode, fs_ch, noise_rms, seed=123):
+    """kappa(noise_rms): how far the ORACLE's own clipped SSB+AGC output moves (RMS) when its input z moves by white
+    noise of the given RMS.  The reference's AGC adds 0.001*(target/|s| - gain) per sample for |s| down to 1e-6
+    (decoders/ssb.py:75-77): a perturbation d of a sample near a zero crossing changes the gain by
+    ~2.5e-4 * d / s^2 and that change decays with a 1000-sample time constant."""
+    rng = np.random.default_rng(seed)
+    dz = (rng.normal(size=z.size) + 1j * rng.normal(size=z.size)) * (noise_rms / np.sqrt(2))
+    a = oracle_demod_chunks(z, chunk_lens, mode, fs_ch)
+    b = oracle_demod_chunks((z + dz).astype(np.complex64), chunk_lens, mode, fs_ch)
+    return rms(a - b)
+
+
+def oracle_ssb_f64_chunks(z, chunk_lens, mode, agc=True):
+    """The SSB decoder's two recurrences in float64 (oracle.cpu_ref.ssb_demod_f64 -- NOT the reference's float32
+    arithmetic), per-chunk gain restarts, clipped like the writer: the comparison target for LOGIC."""
+    st, out, pos = O.DcState(), [], 0
+    for n in chunk_lens:
+        out.append(np.clip(O.ssb_demod_f64(z[pos : pos + n], st, lsb=(mode == "lsb"), agc_enabled=agc), -0.99, 0.99))
+        pos += int(n)
+    return np.concatenate(out) if out else np.empty(0, np.float32)
+
+
+def ssb_agc_evidence(label, z_gpu, audio_gpu, z_ref, audio_ref, chunk_lens, mode, fs_ch, z_tol, strict_replay=False):
+    """SSB with AGC on: localise the GPU-vs-oracle difference BY CAUSE.
+
+    It cannot be localised in TIME: the gain carries every near-zero sample's error for ~1000 samples, so an input
+    perturbation of 1e-7 RMS already moves the reference's own output by more than 1e-4 on about half of all samples
+    (--benchmark capture: 54 % within 1e-4 at 1e-7, 49 % at 3e-7; tests/test_host_logic.py).  The chain is therefore
+    held link by link:
+
+      1. z (channelizer output) against the oracle's z: the usual tight bar ``z_tol`` -- the only place where the two
+         implementations see different numbers;
+      2. LOGIC: the decoder's two recurrences restated in float64 (``oracle_ssb_f64_chunks``), fed with the GPU's own
+         z, must reproduce the GPU's audio to 1e-5 on EVERY sample (same input, same precision: what is left is the
+         order of float64 operations).  A wrong AGC restart index, a wrong state hand-off between blocks or a wrong
+         threshold decision shows up here at the 1e-2 level;
+      3. ROUNDING: the reference runs those recurrences in sequential float32; replaying the GPU's z through THAT
+         arithmetic differs from the GPU's audio by the reference's own rounding amplified by 1/|s| -- measured and
+         printed; with ``strict_replay`` (the --benchmark capture, on which the north-star bar is stated) it must meet
+         the bar itself: >= 99 % of samples within 1e-4, median <= 1e-6, RMS < 1e-4;
+      4. the end-to-end error is then the reference's sensitivity to the z difference of link 1: it must stay below
+         kappa evaluated AT that difference (never below the 3e-7 of float32 rounding).
+    Returns the measured numbers (DESIGN.md section 5 quotes them)."""
+    assert z_gpu.shape == z_ref.shape and audio_gpu.shape == audio_ref.shape == (int(np.sum(chunk_lens)),)
+    dz = rms(z_gpu - z_ref)
+    assert dz < z_tol, (label, "z", dz)
+    logic = np.abs(audio_gpu.astype(np.float64) - oracle_ssb_f64_chunks(z_gpu, chunk_lens, mode))
+    replay = oracle_demod_chunks(z_gpu, chunk_lens, mode, fs_ch)
+    e = np.abs(audio_gpu.astype(np.float64) - replay)
+    frac, med, e_rms = float(np.mean(e < 1e-4)), float(np.median(e)), float(np.sqrt(np.mean(e * e)))
+    err = rms(audio_gpu - audio_ref)
+    kappa = agc_sensitivity(z_ref, chunk_lens, mode, fs_ch, max(dz, 3e-7))
+    print(f"SSB+AGC {label}: z rms diff {dz:.2e} | logic (float64 recurrences on the GPU's z): max {logic.max():.2e}, "
+          f"rms {np.sqrt(np.mean(logic ** 2)):.2e} | rounding (reference float32 loops on the GPU's z): rms {e_rms:.2e}, "
+          f"median {med:.2e}, within 1e-4: {100 * frac:.3f} %, max {e.max():.2e} | end-to-end rms {err:.2e} vs "
+          f"kappa({max(dz, 3e-7):.1e}) = {kappa:.2e}")
+    assert logic.max() < 1e-5, (label, "logic", float(logic.max()))
+    if strict_replay:
+        assert frac >= 0.99, (label, "replay fraction", frac)
+        assert med <= 1e-6, (label, "replay median", med)
+        assert e_rms < 1e-4, (label, "replay rms", e_rms)
+    else:
+        assert e_rms < 1e-3 and frac > 0.9, (label, "replay", e_rms, frac)
+    assert err < kappa + 2e-5, (label, "end-to-end", err, kappa)
+    return dict(dz=dz, logic_max=float(logic.max()), replay_rms=e_rms, replay_median=med, replay_frac=frac, err=err, kappa=kappa)
+
+
+def chunk_lens_for(n_frames, chunk, d, n_dec):
+    starts = -(-np.arange(0, n_frames, chunk, dtype=np.int64) // d)
+    return np.diff(np.append(starts, n_dec))
+
+
+def test_ssb_agc_same_input_full_c1(A, golden):
+    """BASELINE config 1 at full size, USB and LSB with AGC on, through the fused block path (Channelizer +
+    ChannelDemod, two device blocks so that the DC-blocker state crosses a block edge and the AGC restarts fall both
+    inside and at the start of a block).  Held by cause (``ssb_agc_evidence``), plus the gain trajectory: the
+    pluggable decoder (unclipped output) fed with the oracle's own z chunk by chunk must end every chunk with the
+    oracle's gain."""
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.processing import ChannelDemod
+
+    g = golden("c1_full_scalars.npz")
+    fs, f_off, chunk = float(g["fs"]), float(g["f_off"]), int(g["chunk"])
+    raw = O.synth_capture_s16(fs, float(g["seconds"]), f_off)
+    n = raw.shape[0]
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    flat = raw.reshape(-1)
+    for mode in ("usb", "lsb"):
+        want = O.run_chain(raw, sample_rate=fs, freq_offset=f_off, demod_mode=mode, keep_decimated=True)
+        ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
+        dem = ChannelDemod(mode, fs_ch, deemph_us=300.0, agc_enabled=True)
+        n_dec = -(-n // d)
+        audio, zs, pos = D.empty(n_dec, "float32"), [], 0
+        step = 7 * chunk  # 7 + 5 chunks
+        for lo in range(0, n, step):
+            hi = min(lo + step, n)
+            z = ch.process(D.to_device(flat[2 * lo : 2 * hi], "int16"))
+            dem.process(z, P.chunk_output_starts(chunk, d, lo, hi - lo), audio[pos : pos + z.numel()])
+            zs.append(z)
+            pos += z.numel()
+        import torch
+
+        z_gpu = torch.cat(zs).cpu().numpy()
+        got = audio.cpu().numpy()
+        assert got.size == want.audio.size == int(g[mode + "_n"]) == 480_770
+        lens = chunk_lens_for(n, chunk, d, n_dec)
+        assert len(lens) == 12
+        ev = ssb_agc_evidence(f"C1 {mode}", z_gpu, got, want.decimated, want.audio, lens, mode, fs_ch, z_tol=2e-5,
+                              strict_replay=True)
+        assert ev["err"] < agc_sensitivity(want.decimated, lens, mode, fs_ch, 3e-7) + 2e-5  # what round 1 held at 5 kappa
+        assert abs(rms(got) - float(g[mode + "_rms"])) < 0.01 * float(g[mode + "_rms"])
+        np.testing.assert_allclose(dem.chunk_rms_dbfs(), want.rms_dbfs, atol=0.5)
+        # gain trajectory: same input (the ORACLE's z), unclipped outputs of the pluggable decoder, every chunk.
+        # Against the float64 recurrences the gain at each chunk's end must agree to 1e-5 (logic); against the
+        # reference's float32 loops the unclipped audio must agree within 1e-4 (relative to the output's own excursion,
+        # peak 42 on this capture) on >= 99 % of the samples (rounding).
+        dec = A.create_decoder(mode, deemph_us=300.0, agc_enabled=True)
+        dec.setup(fs_ch)
+        st32, st64 = O.DemodState(mode, fs_ch), O.DcState()
+        pos, close = 0, []
+        for k, ln in enumerate(lens):
+            zc = want.decimated[pos : pos + ln]
+            y_gpu, _ = dec.process(zc)
+            y_ref, _ = O.demodulate(zc, st32)
+            y_64 = O.ssb_demod_f64(zc, st64, lsb=(mode == "lsb"))
+            s_gpu = dec.intermediates()["dc_block"][0]
+            tail = slice(ln - 64, ln)
+            ok = np.abs(s_gpu[tail]) > 1e-4
+            gain_gpu = np.median(y_gpu[tail][ok].astype(np.float64) / s_gpu[tail][ok])
+            gain_64 = np.median(y_64[tail][ok].astype(np.float64) / s_gpu[tail][ok])
+            assert abs(gain_gpu - gain_64) <= 1e-5 * abs(gain_64), (mode, k, gain_gpu, gain_64)
+            assert np.abs(y_gpu.astype(np.float64) - y_64).max() <= 1e-5 * max(1.0, float(np.abs(y_64).max())), (mode, k)
+            e = np.abs(y_gpu.astype(np.float64) - y_ref)
+            close.append(e < 1e-4 * np.maximum(1.0, np.abs(y_ref)))
+            assert np.mean(close[-1]) >= 0.95, (mode, k)  # (the float64 statement itself: 97.1 % on the worst chunk)
+            pos += int(ln)
+        assert np.mean(np.concatenate(close)) >= 0.99, mode
+
+
+# ---- BASELINE config 3 as a workload ---------------------------------------------------------------
+
+C3_FS = 20e6
+C3_TARGETS = [  # (offset Hz, amplitude, generator mode), (demod mode, bandwidth): SURVEY.md section 8(d)
+    ((25e3, 0.14, "nfm"), ("nfm", 12_500.0)),
+    ((-150e3, 0.14, "am"), ("am", 10_000.0)),
+    ((400e3, 0.14, "usb"), ("usb", 2_800.0)),
+    ((-1.1e6, 0.14, "lsb"), ("lsb", 2_800.0)),
+    ((2.3e6, 0.14, "nfm"), ("nfm", 12_500.0)),
+]
+
+
+def test_config3_workload_five_mixed_targets_agc_on(A, tmp_path):
+    """BASELINE config 3: 20 MS/s, five simultaneous --ft targets (NFM 12.5 k / AM 10 k / USB 2.8 k / LSB 2.8 k /
+    NFM 12.5 k: 12 801 / 16 001 / 32 769 / 32 769 / 12 801 taps, i.e. 1 + 2 + 3 + 3 + 1 tap-row groups), AGC on,
+    D = 208, chunk 4 194 304 -- 0.55 s of the build-defined five-carrier capture through
+    MultiChannelPipeline in three device blocks, every channel against its own single-target oracle chain: exact
+    counts, signs, NFM/AM audio < 2e-5 RMS, SSB+AGC held by cause, 48 kHz PCM16 of NFM/AM within 1 LSB."""
+    from iq_to_audio_amd import iqio
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+
+    fs, secs, fc = C3_FS, 0.55, 433.0e6
+    raw = synthetic_multi_iq_s16(fs, secs, [c for c, _ in C3_TARGETS])
+    n = raw.shape[0]
+    wav = tmp_path / "c3_433000000Hz.wav"
+    iqio.write_wav_iq(wav, raw, int(fs), "s16")
+    cfgs = [A.ProcessingConfig(in_path=wav, target_freq=fc + off, bandwidth=bw, demod_mode=mode, agc_enabled=True,
+                               output_path=tmp_path / f"c3_{i}.wav", dump_iq_path=tmp_path / f"c3_{i}.cf32")
+            for i, ((off, _, _), (mode, bw)) in enumerate(C3_TARGETS)]
+    multi = A.MultiChannelPipeline(cfgs)
+    for o in multi.owners:
+        o.keep_channel_audio = True
+        o.block_frames_target = 4_194_304  # one reference chunk per device block: 3 blocks
+    results = multi.run()
+    assert len(results) == 5
+    chunk = 4_194_304
+    for i, (((off, _, _), (mode, bw)), res, owner) in enumerate(zip(C3_TARGETS, results, multi.owners)):
+        want = O.run_chain(raw, sample_rate=fs, freq_offset=off, bandwidth=bw, demod_mode=mode, agc_enabled=True)
+        got = owner.audio_fs_channel.cpu().numpy()
+        assert res.decimation == want.decimation == 208 and want.chunk == chunk
+        assert got.size == want.audio.size == -(-n // 208)  # sample count: exact
+        assert res.mix_sign == want.mix_sign
+        assert abs(res.freq_offset - off) < 1e-3
+        assert want.ntaps == {12_500.0: 12_801, 10_000.0: 16_001, 2_800.0: 32_769}[bw]
+        z_gpu = np.fromfile(tmp_path / f"c3_{i}.cf32", dtype=np.complex64)
+        assert z_gpu.size == want.decimated.size
+        if mode in ("usb", "lsb"):
+            lens = chunk_lens_for(n, chunk, 208, got.size)
+            ssb_agc_evidence(f"C3 {mode} {off:+.0f} Hz", z_gpu, got, want.decimated, want.audio, lens, mode,
+                             want.fs_channel, z_tol=5e-5)
+            assert rms(want.audio) > 0.05
+            continue
+        assert rms(z_gpu - want.decimated) < 3e-5, (mode, off)
+        err = rms(got - want.audio)
+        print(f"C3 {mode} {off:+.0f} Hz: audio rms err {err:.2e} (signal rms {rms(want.audio):.3f})")
+        assert err < 1e-4, (mode, off, err)  # the north-star bar
+        assert err < 2e-5, (mode, off, err)  # what we hold
+        assert rms(want.audio) > 1e-3  # the channel carries its signal
+        assert abs(res.audio_peak - want.audio_peak) < 2e-4 * max(1.0, want.audio_peak)
+        pcm, rate = iqio.read_wav_pcm16_mono(tmp_path / f"c3_{i}.wav")
+        ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+        assert rate == 48000 and pcm.size == ref48.size
+        assert np.max(np.abs(pcm.astype(np.int32) - ref48.astype(np.int32))) <= 1
+
+
+# ---- BASELINE config 5's per-GPU unit --------------------------------------------------------------
+
+C5_FS = 50e6
+
+
+def c5_carriers():
+    """40 NFM carriers on a 100 kHz raster from -1.95 MHz, amplitude 0.02 each."""
+    return [(-1.95e6 + 100e3 * k, 0.02, "nfm") for k in range(40)]
+
+
+def test_config5_unit_five_nfm_channels(A, tmp_path):
+    """BASELINE config 5, one GPU's share: 50 MS/s, D = 521 (fs_ch 95 969.29 Hz, 32 001 taps, 33 k steps in three
+    passes), five of the 40 NFM channels (first, second, the two around DC, last) with de-emphasis, 0.42 s, through
+    MultiChannelPipeline (demodulator + 48 kHz resampler with up/down = 48 000/95 969) against the oracle.
+    The carriers are weak (0.02 of full scale, 34 dB below the wideband total): this is also the weak-channel case
+    for the fixed-point channelizer."""
+    from iq_to_audio_amd import iqio
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+
+    fs, secs, fc = C5_FS, 0.42, 1.0e9
+    carriers = c5_carriers()
+    raw = synthetic_multi_iq_s16(fs, secs, carriers)
+    n = raw.shape[0]
+    path = tmp_path / "c5_1000000000Hz.cs16"
+    path.write_bytes(raw.tobytes())
+    picks = [0, 1, 19, 20, 39]
+    cfgs = [A.ProcessingConfig(in_path=path, target_freq=fc + carriers[k][0], bandwidth=12_500.0, demod_mode="nfm",
+                               deemph_us=300.0, input_sample_rate=fs, output_path=tmp_path / f"c5_{k}.wav",
+                               dump_iq_path=tmp_path / f"c5_{k}.cf32") for k in picks]
+    multi = A.MultiChannelPipeline(cfgs)
+    for o in multi.owners:
+        o.keep_channel_audio = True
+        o.block_frames_target = 3 * 4_194_304  # two device blocks (3 + 3 chunks; 21 M frames = 5.01 chunks)
+    results = multi.run()
+    problems = []  # tolerance misses are collected so that one run shows every channel's numbers
+    for k, res, owner in zip(picks, results, multi.owners):
+        off = carriers[k][0]
+        want = O.run_chain(raw, sample_rate=fs, freq_offset=off, bandwidth=12_500.0, demod_mode="nfm")
+        assert (res.decimation, want.decimation, want.ntaps) == (521, 521, 32_001)
+        assert abs(res.fs_channel - 50e6 / 521) < 1e-9
+        got = owner.audio_fs_channel.cpu().numpy()
+        assert got.size == want.audio.size == -(-n // 521)
+        assert res.mix_sign == want.mix_sign  # (the raster is symmetric: the mirror carrier has the same power)
+        z_gpu = np.fromfile(tmp_path / f"c5_{k}.cf32", dtype=np.complex64)
+        dz = rms(z_gpu - want.decimated)
+        err = rms(got - want.audio)
+        print(f"C5 channel {k} ({off:+.0f} Hz): z rms diff {dz:.2e} (|z| rms {rms(want.decimated):.3e}), "
+              f"audio rms err {err:.2e} (signal rms {rms(want.audio):.3f})")
+        if not dz < 5e-6:
+            problems.append((k, "z", dz))
+        if not err < 1e-4:  # the north-star bar on a channel 34 dB below full scale
+            problems.append((k, "audio", err))
+        assert rms(want.audio) > 1e-2
+        pcm, rate = iqio.read_wav_pcm16_mono(tmp_path / f"c5_{k}.wav")
+        ref48 = O.resample_48k(want.audio, want.fs_channel)
+        assert rate == 48000 and pcm.size == ref48.size == -(-got.size * 48000 // 95969)
+        # PCM16 of the GPU's own audio through the oracle's resampler: the resampler/quantiser link, 1 LSB
+        own48 = O.float_to_pcm16(O.resample_48k(got, want.fs_channel))
+        assert np.max(np.abs(pcm.astype(np.int32) - own48.astype(np.int32))) <= 1
+        assert rms(pcm.astype(np.float64) / 32768.0 - ref48) < 1e-4 + (1.0 if problems else 0.0)
+    assert not problems, problems

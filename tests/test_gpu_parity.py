@@ -212,18 +212,27 @@ def test_decoders_chunked_vs_oracle(A, mode):
     fs_ch = 96153.84615384616
     dec = A.create_decoder(mode, deemph_us=300.0, agc_enabled=True)
     dec.setup(fs_ch)
-    st = O.DemodState(mode, fs_ch)
+    st, st64 = O.DemodState(mode, fs_ch), O.DcState()
     for lo, hi in ((0, 9000), (9000, 9001), (9001, 30000)):
         got, stats = dec.process(z[lo:hi])
         want, db = O.demodulate(z[lo:hi], st)
         assert got.shape == want.shape and got.dtype == np.float32
         got_c, want_c = np.clip(got, -0.99, 0.99), np.clip(want, -0.99, 0.99)
-        bound = 2e-5
-        if mode in ("usb", "lsb") and hi - lo > 1:
-            # AGC on: bounded by the oracle's own sensitivity to float32-rounding-sized input noise
-            bound += 5 * agc_sensitivity(z[lo:hi], [hi - lo], mode, fs_ch, noise_rms=1e-7)
-        assert rms(got_c - want_c) < bound, (mode, rms(got_c - want_c), bound)
-        assert abs(stats.rms_dbfs - db) < (0.2 if mode in ("usb", "lsb") else 1e-3)
+        if mode in ("usb", "lsb"):
+            # AGC on, IDENTICAL input.  Logic: the two recurrences restated in float64 (same restart per call, same
+            # threshold, DC state carried) must agree with the GPU on every sample.  Rounding: the reference's float32
+            # loops differ from that by their own rounding amplified by 1/|s| -- on this white-noise input (|s| crosses
+            # zero at random every other sample) 1.5e-4 .. 3.7e-4 RMS between the oracle's own float32 and float64
+            # statements, so that is all the float32 comparison can hold.
+            y64 = O.ssb_demod_f64(z[lo:hi], st64, lsb=(mode == "lsb"))
+            assert np.abs(got.astype(np.float64) - y64).max() <= 1e-5 * max(1.0, float(np.abs(y64).max())), (mode, lo)
+            db64 = 20.0 * np.log10(np.sqrt(np.mean(y64.astype(np.float64) ** 2) + 1e-18) + 1e-12)
+            assert abs(stats.rms_dbfs - db64) < 1e-3
+            assert rms(got_c - want_c) < 2e-5 + 3.0 * rms(np.clip(y64, -0.99, 0.99) - want_c), (mode, lo)
+            assert abs(stats.rms_dbfs - db) < 0.05
+            continue
+        assert rms(got_c - want_c) < 2e-5, (mode, rms(got_c - want_c))
+        assert abs(stats.rms_dbfs - db) < 1e-3
     assert set(dec.intermediates()) >= {"audio"}
 
 
@@ -293,7 +302,8 @@ def test_channelizer_long_filters(A, fs, bw, d, f_off):
 # ---- whole chain ---------------------------------------------------------------------------------
 
 
-def _gpu_chain(A, raw, *, fs, f_off, bw, mode, chunk, agc=True, order="iq", sign=None, fmt="s16", block_chunks=3):
+def _gpu_chain(A, raw, *, fs, f_off, bw, mode, chunk, agc=True, order="iq", sign=None, fmt="s16", block_chunks=3,
+               want_z=False):
     """Pipeline body on in-memory frames: Channelizer + ChannelDemod over blocks of whole chunks."""
     from iq_to_audio_amd import dsp_plan as P
     from iq_to_audio_amd import _dev as D
@@ -308,14 +318,18 @@ def _gpu_chain(A, raw, *, fs, f_off, bw, mode, chunk, agc=True, order="iq", sign
     ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=sign, decimation=d, fmt=fmt, iq_order=order)
     dem = ChannelDemod(mode, fs_ch, deemph_us=300.0, agc_enabled=agc)
     audio = D.empty(-(-n // d), "float32")
-    pos = 0
+    pos, zs = 0, []
     step = chunk * block_chunks
     for lo in range(0, n, step):
         hi = min(lo + step, n)
         z = ch.process(D.to_device(flat[2 * lo : 2 * hi], "int16" if fmt == "s16" else "uint8"))
         starts = P.chunk_output_starts(chunk, d, lo, hi - lo)
         dem.process(z, starts, audio[pos : pos + z.numel()])
+        if want_z:
+            zs.append(z.cpu().numpy())
         pos += z.numel()
+    if want_z:
+        return audio[:pos].cpu().numpy(), sign, dem, np.concatenate(zs)
     return audio[:pos].cpu().numpy(), sign, dem
 
 
@@ -334,20 +348,22 @@ def test_small_capture_against_reference_fixtures(A, golden):
             mode, override = "nfm", (-1 if order != "iq" else None)
         else:
             order, mode, override = "iq", key.split("_")[0], None
-        got, got_sign, dem = _gpu_chain(A, raw, fs=fs, f_off=float(f_off), bw=float(bw), mode=mode, chunk=int(chunk),
-                                        agc=bool(agc), order=order, sign=override)
+        got, got_sign, dem, z_got = _gpu_chain(A, raw, fs=fs, f_off=float(f_off), bw=float(bw), mode=mode, chunk=int(chunk),
+                                               agc=bool(agc), order=order, sign=override, want_z=True)
         want = g[key + "_audio"]
         assert got.shape == want.shape, key  # sample count exact
         assert got_sign == int(sign), key
         err = rms(got - want)
         if mode in ("usb", "lsb") and bool(agc):
-            # ill-conditioned by construction (see agc_sensitivity): bound by the oracle's own sensitivity
+            # ill-conditioned in the reference itself: held link by link (test_gpu_configs.ssb_agc_evidence) against
+            # the oracle's z and audio of the same case
+            from test_gpu_configs import chunk_lens_for, ssb_agc_evidence
+
             ref = O.run_chain(raw, sample_rate=fs, freq_offset=float(f_off), bandwidth=float(bw), demod_mode=mode,
                               chunk_size=int(chunk), filter_block=int(block), tune_chunk=False)
-            lens = np.diff(np.append(P.chunk_output_starts(int(chunk), int(d), 0, raw.shape[0]), ref.decimated.size))
-            kappa = agc_sensitivity(ref.decimated, lens, mode, ref.fs_channel)
-            assert err < 5 * kappa + 2e-5, (key, err, kappa)
-            worst_agc = max(worst_agc, err)
+            lens = chunk_lens_for(raw.shape[0], int(chunk), int(d), ref.decimated.size)
+            ev = ssb_agc_evidence(f"fixture {key}", z_got, got, ref.decimated, ref.audio, lens, mode, ref.fs_channel, z_tol=2e-5)
+            worst_agc = max(worst_agc, ev["err"])
             continue
         worst = max(worst, err)
         assert err < 1e-4, (key, err)  # the north_star bar
@@ -364,8 +380,8 @@ def test_c1_full_length_against_reference_scalars(A, golden, mode):
     fs, f_off = float(g["fs"]), float(g["f_off"])
     raw = O.synth_capture_s16(fs, float(g["seconds"]), f_off)
     chunk = int(g["chunk"])
-    got, sign, dem = _gpu_chain(A, raw, fs=fs, f_off=f_off, bw=12500.0, mode=mode, chunk=chunk, block_chunks=5)
-    from iq_to_audio_amd import dsp_plan as P
+    got, sign, dem, z_got = _gpu_chain(A, raw, fs=fs, f_off=f_off, bw=12500.0, mode=mode, chunk=chunk, block_chunks=5,
+                                       want_z=True)
 
     assert got.size == int(g[mode + "_n"]) == 480_770  # sample count: exact
     assert sign == int(g[mode + "_sign"]) == 1
@@ -374,12 +390,15 @@ def test_c1_full_length_against_reference_scalars(A, golden, mode):
     assert len(db) == len(want.rms_dbfs) == 12
     if mode in ("usb", "lsb"):
         # SSB + AGC on this capture (carrier at DC -> DC-blocked residue crossing zero all the time) is
-        # ill-conditioned in the REFERENCE: float32-rounding-sized input noise moves its output by kappa.
-        lens = np.diff(np.append(P.chunk_output_starts(chunk, 26, 0, raw.shape[0]), want.decimated.size))
-        kappa = agc_sensitivity(want.decimated, lens, mode, want.fs_channel)
-        err = rms(got - want.audio)
-        print(f"{mode}: gpu-vs-oracle rms {err:.3e}; oracle self-sensitivity kappa {kappa:.3e}")
-        assert err < 5 * kappa + 2e-5
+        # ill-conditioned in the REFERENCE: held link by link (z / logic / rounding / sensitivity), with the strict
+        # replay bar (>= 99 % of samples within 1e-4, median <= 1e-6, RMS < 1e-4 against the reference's own float32
+        # loops on the same input) because this is the capture the north-star bar is stated on.
+        from test_gpu_configs import chunk_lens_for, ssb_agc_evidence
+
+        lens = chunk_lens_for(raw.shape[0], chunk, 26, want.decimated.size)
+        ev = ssb_agc_evidence(f"C1 {mode} (3 blocks)", z_got, got, want.decimated, want.audio, lens, mode, want.fs_channel,
+                              z_tol=2e-5, strict_replay=True)
+        assert ev["err"] < agc_sensitivity(want.decimated, lens, mode, want.fs_channel) + 2e-5  # kappa(3e-7), not 5 kappa
         assert abs(rms(got) - float(g[mode + "_rms"])) < 0.01 * float(g[mode + "_rms"])
         np.testing.assert_allclose(db, want.rms_dbfs, atol=0.5)
         # with the AGC off the same path is well-conditioned and meets the tight bar

@@ -399,3 +399,62 @@ def test_taps_fingerprint_and_runtime_defaults():
     assert w1[0] is not w2[0] and w1[0] != w2[0]
     view = frozen[:100]  # a read-only VIEW is not trusted (its base could change hands)
     assert PR._taps_fingerprint(view)[0] is not PR._taps_fingerprint(view)[0]
+
+
+# ---- side paths: slice encodings and the benchmark's tone placement (host logic, no GPU) --------------
+
+
+def test_slice_encodings_follow_the_reference_rules():
+    """reference processing.py:527-539 for headerless slices (s16: limit to [-1, 0.999969], x 32767, truncate toward
+    zero; u8: limit to [-1, 1], (x + 1) * 127.5, round half to even; f32: as is); WAV slices follow libsndfile's
+    normalised float -> PCM rule (third-party: parity unpinned)."""
+    from iq_to_audio_amd import iqio
+
+    z = np.array([0.0 + 0.5j, -1.5 + 1.5j, 0.999969 - 0.25j, 1e-5 - 1e-5j, 0.3333 + 0.0039215j], dtype=np.complex64)
+    flat = np.array([v for c in z for v in (c.real, c.imag)], dtype=np.float32)
+    np.testing.assert_array_equal(iqio.encode_iq_slice(z, "pcm_f32le"), flat)
+    s16 = iqio.encode_iq_slice(z, "pcm_s16le", "raw")
+    assert s16.dtype == np.dtype("<i2")
+    want = [int(np.float32(min(max(v, -1.0), 0.999969)) * np.float32(32767.0)) for v in flat]  # int() truncates
+    assert s16.tolist() == want and s16[2] == -32767 and s16[3] == 32765 and s16[6] == 0 and s16[7] == 0
+    u8 = iqio.encode_iq_slice(z, "pcm_u8", "raw")
+    assert u8.dtype == np.uint8 and u8.tolist()[:4] == [128, 191, 0, 255]  # 127.5 -> 128 and 191.25 -> 191 (half to even)
+    w16 = iqio.encode_iq_slice(z, "pcm_s16le", "wav")
+    assert w16.tolist()[:4] == [0, 16384, -32768, 32767] and w16[6] == 0  # rint(0.5 * 32767) = 16384 (half to even)
+    w8 = iqio.encode_iq_slice(z, "pcm_u8", "wav")
+    assert w8.tolist()[:4] == [128, 192, 0, 255]
+    with pytest.raises(ValueError):
+        iqio.encode_iq_slice(z, "pcm_s24le")
+
+
+def test_run_benchmark_places_the_tone_like_the_reference(monkeypatch):
+    """reference benchmark.py:61-72: centre AND target given -> the tone sits at target - centre (freq_offset is only
+    range-checked); one of them given -> the other follows from freq_offset; neither -> centre 400 MHz."""
+    from iq_to_audio_amd import benchmark as B
+
+    seen = {}
+
+    def fake_generate(path, sample_rate, seconds, freq_offset, **kw):
+        seen.update(path=path, offset=freq_offset)
+
+    class FakePipeline:
+        def __init__(self, config):
+            seen["config"] = config
+
+        def run(self, progress_sink=None):
+            return A.ProcessingResult(None, seen["config"].center_freq, seen["config"].target_freq, 0.0, 26, 96153.8, 1, 0.5)
+
+    monkeypatch.setattr(B, "_generate_synthetic_iq", fake_generate)
+    monkeypatch.setattr(B, "ProcessingPipeline", FakePipeline)
+    kw = dict(seconds=1.0, sample_rate=2.5e6, freq_offset=25e3, base_kwargs={"demod_mode": "AM", "probe_only": True})
+    assert B.run_benchmark(center_freq=4.0e8, target_freq=4.0004e8, **kw) == 0
+    cfg = seen["config"]
+    assert seen["offset"] == 40e3 and (cfg.center_freq, cfg.target_freq) == (4.0e8, 4.0004e8)
+    assert cfg.demod_mode == "am" and cfg.probe_only is False and cfg.center_freq_source == "benchmark"
+    assert seen["path"].name == "benchmark_fc-400000000Hz.wav" and cfg.output_path.name == "benchmark_audio_am.wav"
+    B.run_benchmark(center_freq=1.0e8, target_freq=None, **kw)
+    assert seen["offset"] == 25e3 and seen["config"].target_freq == 1.0e8 + 25e3
+    B.run_benchmark(center_freq=None, target_freq=1.0e8, **kw)
+    assert seen["offset"] == 25e3 and seen["config"].center_freq == 1.0e8 - 25e3
+    B.run_benchmark(center_freq=None, target_freq=None, **kw)
+    assert seen["offset"] == 25e3 and (seen["config"].center_freq, seen["config"].target_freq) == (4.0e8, 4.0e8 + 25e3)
