@@ -878,6 +878,7 @@ class ProcessingPipeline:
         self.chunk_rms_dbfs: list[float] = []
         self.audio_fs_channel = None  # device float32 tensor of the clipped channel-rate audio (kept for tests)
         self.keep_channel_audio = False
+        self.channelizer_kernel = None  # name of the channelizer kernel that produced the last block of the run
 
     def cancel(self) -> None:
         self._cancelled = True
@@ -983,6 +984,7 @@ class _Target:
 
     def finish(self) -> None:
         cfg, info = self.cfg, self.info
+        self.owner.channelizer_kernel = self.chan._kernel.last_kernel
         self.output_path.parent.mkdir(parents=True, exist_ok=True)
         if cfg.dump_iq_path:
             Path(cfg.dump_iq_path).write_bytes(self.z_all[: self.pos_dec].cpu().numpy().astype(np.complex64).tobytes())

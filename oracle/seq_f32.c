@@ -89,20 +89,23 @@ void agc_f32(const float *x, float *y, size_t n, double target, double decay)
  * crosses block edges: must agree with the GPU to ~1e-6) from ROUNDING (float32 sequential in the reference, float64
  * scans on the GPU: amplified by the AGC's 1/|s|, see tests/test_gpu_configs.py::ssb_agc_evidence).
  * Interfaces mirror the float32 functions: float32 samples in and out, the DC-blocked sample is rounded to float32
- * before the AGC sees it (as both implementations store it), the threshold test is the float32 one.
+ * before the AGC sees it (as both implementations store it), the threshold test and target/|s| are the float32 ones.
  */
 void dc_block_f64(const float *x, float *y, size_t n, double r, double *x_prev_io, double *y_prev_io)
 {
-    double xp = *x_prev_io, yp = *y_prev_io;
+    /* the input difference x[n] - x[n-1] is formed in float32, exactly as the reference forms it (decoders/common.py:24,
+       two np.float32 operands); only the recurrence on y runs in float64 */
+    float xp = (float)(*x_prev_io);
+    double yp = *y_prev_io;
     const double rr = (double)(float)r;
     for (size_t i = 0; i < n; ++i) {
-        const double s = (double)x[i];
-        const double out = s - xp + rr * yp;
+        const float diff = x[i] - xp;
+        const double out = (double)diff + rr * yp;
         y[i] = (float)out;
-        xp = s;
+        xp = x[i];
         yp = out;
     }
-    *x_prev_io = xp;
+    *x_prev_io = (double)xp;
     *y_prev_io = yp;
 }
 
@@ -115,7 +118,7 @@ void agc_f64(const float *x, float *y, size_t n, double target, double decay)
         const float s = x[i];
         const float mag = fabsf(s);
         if (mag > thr)
-            gain += df * (tf / (double)mag - gain);
+            gain += df * ((double)((float)tf / mag) - gain);
         y[i] = (float)((double)s * gain);
     }
 }

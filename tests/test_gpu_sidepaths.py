@@ -93,9 +93,10 @@ def test_pass_through_slice_keeps_container_and_codec(A, tmp_path, container, fm
     if fmt == "f32":
         np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)
     else:
-        # z differs from the oracle's by ~1e-6: a value next to a quantisation step may land on the other side
+        # z differs from the oracle's by ~2e-6 RMS (matrix-core channelizer): a value next to a quantisation step may
+        # land on the other side -- 3.5 % of the int16 values (step 3.05e-5), 0.03 % of the uint8 ones
         diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-        assert diff.max() <= 1 and np.mean(diff != 0) < (0.02 if fmt == "s16" else 2e-3)
+        assert diff.max() <= 1 and np.mean(diff != 0) < (0.08 if fmt == "s16" else 2e-3)
 
 
 def test_dump_iq_is_the_decimated_stream(A, tmp_path):
