@@ -126,10 +126,10 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
 typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
     int32_t reserved;          /* data-path variant + diagnostics flags.  0 = per-lane row loads; 64 = block-wide
-                                * LDS-DMA ring, 64-bit sums (needs iqa_mfma_ring_mode(D, k_first, k_count, 0) != 0;
+                                * LDS-DMA ring, 64-bit sums (needs iqa_mfma_ring_mode(fmt, D, k_first, k_count, 0) != 0;
                                 * its LDS does not depend on outputs_per_block); 64|128 = the ring with 256*S1 + S2
                                 * in one int32, for fragments from a quantisation that bounds that sum
-                                * (dsp_plan.plan_mfma(acc32=True); iqa_mfma_ring_mode(..., 1) != 0);
+                                * (dsp_plan.plan_mfma(acc32=True); iqa_mfma_ring_mode(fmt, D, k_first, k_count, 1) != 0);
                                 * bits 0,1,4,5 are timing diagnostics, never set in production */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
@@ -158,6 +158,39 @@ int32_t iqa_mfma_ring_mode(int32_t fmt, int32_t decimation, int32_t k_first, int
 int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, const void *afrag_dev,
                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first, int64_t n_out,
                         void *z_out_dev, void *stream);
+
+/*
+ * Several channels of ONE capture in one launch of the ring kernel (shared ingest).
+ * ref: the reference CLI runs a whole pipeline per --ft target over the same file (cli.py:683-710, at most five
+ * targets :514-521); here every (channel, tap-row group) is a LANE of one launch: the lanes share the capture, the
+ * decimation, the k-step range and the output range, and differ in their tap fragments, scale, rotation and output.
+ * Lanes of the same stretch of the capture run at the same time on the CUs of one XCD, so the stretch crosses the
+ * fabric once (channelize_ring.hip).  int32 sums only: fragments from dsp_plan.plan_mfma(acc32=True);
+ * iqa_mfma_ring_mode(fmt, D, k_first, k_count, 1) must be non-zero.  At most 16 lanes per call.
+ * A filter with several tap-row groups is several lanes with finalize = 0, each writing its raw sums to its own
+ * partial_out_dev; iqa_mfma_combine adds them in group order and finishes z.  A decimation whose k steps need several
+ * passes is several calls chained through partial_in_dev / partial_out_dev per lane, as with iqa_channelize_mfma.
+ * outputs_per_block: multiple of 32; the launch has 8*ceil(ceil(n_out/outputs_per_block)/8)*n_lanes workgroups -- one
+ * workgroup per CU (256) when ceil(n_out/outputs_per_block) = 8*floor(32/n_lanes).
+ */
+typedef struct {
+    const void *afrag_dev;      /* this lane's tap fragments, first k step of the pass (as for iqa_channelize_mfma) */
+    void *z_out_dev;            /* finalize != 0: float2[n_out] */
+    const void *partial_in_dev; /* double2[n_out] raw sums of this lane's earlier k-step passes, or NULL */
+    void *partial_out_dev;      /* finalize == 0: double2[n_out] */
+    double unit, c_re, c_im;    /* as in iqa_mfma_params */
+    uint64_t rot_step, rot_base;        /* as in iqa_chan_params */
+    float out_scale_re, out_scale_im;
+    int32_t q_group, finalize, conj_sum, rotate;
+} iqa_mfma_lane;
+int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
+                              int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
+                              const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
+                              int64_t n_out, void *stream);
+/* z[m_first + i] = finish(sum_k partials_dev[k][i]): the float32 conversion, conjugation, rotation and scaling of the
+ * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..8 buffers of double2[n_out]. */
+int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials, int64_t m_first,
+                     int64_t n_out, void *z_out_dev, void *stream);
 
 /* Copy the last L-1 frames of (hist | raw) into hist (handles n_frames < L-1 by shifting).
  * ref: OverlapSaveFIR.process state update, processing.py:341-345.

@@ -23,6 +23,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from . import _native as native  # noqa: F401
 from .decoders import Decoder, DecoderStats, create_decoder  # noqa: F401
 from .processing import (  # noqa: F401
+    ChannelBank,
     Channelizer,
     ComplexOscillator,
     Decimator,

@@ -32,6 +32,7 @@
 //   A[row=l&31][k=16(l>>5)+j], B[k=16(l>>5)+j][col=l&31], C: col=l&31, row=(r&3)+8(r>>2)+4(l>>5).
 #include "mfma_common.h"
 
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -319,16 +320,172 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
     if (ring) {
-        mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2, u8);
-        return check_launch("k_channelize_mfma_s16_ring");
+        return mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2, u8);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    {
+        // the 160 KiB dynamic-LDS limit is a per-device attribute (one bit per device id; racing threads both set it)
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_mfma_s16),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) {
+                set_error("k_channelize_mfma_s16: cannot raise the dynamic LDS limit on device %d: %s", dev, hipGetErrorString(e));
+                return IQA_EHIP;
+            }
+            done.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(k_channelize_mfma_s16, dim3(static_cast<unsigned>(blocks)), dim3(MF_THREADS), lds,
                        as_stream(stream), a);
     return check_launch("k_channelize_mfma_s16");
+}
+
+// ---- several lanes (channels x tap-row groups) of one capture in ONE launch of the ring kernel ------------------------
+
+extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
+                                         int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
+                                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
+                                         int64_t n_out, void *stream)
+{
+    if (lanes == nullptr || n_lanes < 1) return fail_inval("no lanes");
+    const bool u8 = fmt == IQA_FMT_U8;
+    if (fmt != IQA_FMT_S16 && !u8) return fail_inval("the MFMA channelizer takes int16 and uint8 captures only");
+    if (decimation < 1) return fail_inval("bad decimation");
+    const int64_t D = decimation;
+    if (n_out < 0 || n_frames < 0 || m_first < 0) return fail_inval("negative size");
+    if (n_out == 0) return IQA_OK;
+    if (!raw_dev) return fail_inval("NULL device pointer");
+    const int ksteps_all = static_cast<int>((2 * D + 31) / 32);
+    const int ksteps = k_count > 0 ? k_count : ksteps_all - k_first;
+    if (k_first < 0 || ksteps <= 0 || k_first + ksteps > ksteps_all) return fail_inval("bad k-step range");
+    const int range = outputs_per_block;
+    if (range <= 0 || (range & 31)) return fail_inval("outputs_per_block must be a positive multiple of 32");
+    const int ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, false, u8);
+    if (ring_mode == 0) return fail_inval("the ring kernel does not cover this (decimation, k-step range): see iqa_mfma_ring_mode");
+    // every frame any lane touches must lie inside [0, n_frames): the lane with the largest tap-row group reads the
+    // earliest data rows, group 0 the latest (see iqa_channelize_mfma for the geometry)
+    int q_max = 0;
+    for (int i = 0; i < n_lanes; ++i) {
+        if (lanes[i].q_group < 0) return fail_inval("bad q group");
+        if (!lanes[i].afrag_dev) return fail_inval("lane without tap fragments");
+        if (lanes[i].finalize ? !lanes[i].z_out_dev : !lanes[i].partial_out_dev) return fail_inval("lane without an output buffer");
+        q_max = lanes[i].q_group > q_max ? lanes[i].q_group : q_max;
+    }
+    const int64_t blocks = (n_out + range - 1) / range;
+    const int64_t last_cnt = n_out - (blocks - 1) * range;
+    const int64_t last_tiles = (last_cnt + 63 + 31) / 32, full_tiles = (static_cast<int64_t>(range) + 63 + 31) / 32;
+    const int64_t f_min = (m_first - MF_Q - static_cast<int64_t>(MF_Q) * q_max) * D + 1 - consumed;
+    const int64_t tail = ring_mode == 1 ? 512LL * ksteps : 16LL * (k_first + ksteps);  // frames read from a row's first frame
+    const int64_t t_last = m_first + (blocks - 1) * range - MF_Q + (last_tiles - 1) * 32;  // first row of the last tile, group 0
+    const int64_t t_full = blocks > 1 ? m_first + (blocks - 2) * range - MF_Q + (full_tiles - 1) * 32 : t_last;
+    const int64_t row_span = ring_mode == 1 ? 0 : 31;  // row-staged slots fetch each of the tile's 32 rows separately
+    if (f_min < 0 || (t_last + row_span) * D + 1 - consumed + tail > n_frames || (t_full + row_span) * D + 1 - consumed + tail > n_frames)
+        return fail_inval("multi-lane ring launch reads outside the block (use iqa_channelize for the edges)");
+    const size_t lds = mfma_ring_lds_bytes(ksteps, ring_mode == 2, u8);
+    if (lds == 0 || lds > 160 * 1024) return fail_inval("ring + window exceed 160 KiB of LDS");
+
+    MfmaArgs a{};
+    a.raw = static_cast<const int *>(raw_dev);
+    a.consumed = consumed;
+    a.m_lo = m_first;
+    a.n_out = n_out;
+    a.D = static_cast<int>(D);
+    a.ksteps = ksteps;
+    a.range = range;
+    a.k_first = k_first;
+    a.debug = 64 | 128;
+    MfmaLane packed[16];
+    if (n_lanes > 16) return fail_inval("at most 16 lanes per launch");
+    for (int i = 0; i < n_lanes; ++i) {
+        const iqa_mfma_lane &s = lanes[i];
+        MfmaLane &l = packed[i];
+        l.afrag = static_cast<const v4i_t *>(s.afrag_dev);
+        l.out = static_cast<float2 *>(s.z_out_dev);
+        l.partial_in = static_cast<const double2 *>(s.partial_in_dev);
+        l.partial_out = static_cast<double2 *>(s.partial_out_dev);
+        l.unit = s.unit;
+        l.c_re = s.c_re;
+        l.c_im = s.c_im;
+        l.rot_step = s.rot_step;
+        l.rot_base = s.rot_base;
+        const unsigned long long st = s.rot_step * 64ULL;
+        const double turns = static_cast<double>(st >> 11) * (1.0 / 9007199254740992.0);
+        l.rot64_re = std::cos(2.0 * M_PI * turns);
+        l.rot64_im = std::sin(2.0 * M_PI * turns);
+        l.sc_re = s.out_scale_re;
+        l.sc_im = s.out_scale_im;
+        l.col_shift = MF_Q * s.q_group;
+        l.finalize = s.finalize;
+        l.conj_sum = s.conj_sum;
+        l.rotate = s.rotate;
+    }
+    return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr);
+}
+
+// Sum of the partial sums of a filter's tap-row groups (each written by its own lane of a multi-lane launch), then the
+// same conversion, rotation and scaling as the kernels' own emission: z[m_first + i].
+namespace iqa {
+struct CombineArgs {
+    const double2 *part[8];
+    int n_parts;
+    float2 *out;
+    long long m_first, n_out;
+    int conj_sum, rotate;
+    unsigned long long rot_step, rot_base;
+    float sc_re, sc_im;
+};
+
+__global__ __launch_bounds__(256) void k_mfma_combine(CombineArgs a)
+{
+    const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= a.n_out) return;
+    double2 d = a.part[0][i];
+    for (int k = 1; k < a.n_parts; ++k) {  // in group order: the chained single-lane passes add them in this order too
+        const double2 v = a.part[k][i];
+        d.x = v.x + d.x;
+        d.y = v.y + d.y;
+    }
+    float my_re = static_cast<float>(d.x), my_im = static_cast<float>(d.y);
+    if (a.conj_sum) my_im = -my_im;
+    float yr = my_re, yi = my_im;
+    if (a.rotate) {
+        const unsigned long long ph = a.rot_base + static_cast<unsigned long long>(a.m_first + i) * a.rot_step;
+        double sn, cs;
+        sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &sn, &cs);
+        const float cf = static_cast<float>(cs), sf = static_cast<float>(sn);
+        yr = my_re * cf - my_im * sf;
+        yi = my_re * sf + my_im * cf;
+    }
+    a.out[i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+}
+}  // namespace iqa
+
+extern "C" int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials, int64_t m_first,
+                                int64_t n_out, void *z_out_dev, void *stream)
+{
+    if (p == nullptr || partials_dev == nullptr) return fail_inval("params is NULL");
+    if (n_partials < 1 || n_partials > 8) return fail_inval("1..8 partial buffers");
+    if (n_out < 0 || m_first < 0) return fail_inval("negative size");
+    if (n_out == 0) return IQA_OK;
+    if (!z_out_dev) return fail_inval("NULL device pointer");
+    CombineArgs a{};
+    for (int k = 0; k < n_partials; ++k) {
+        if (!partials_dev[k]) return fail_inval("NULL partial buffer");
+        a.part[k] = static_cast<const double2 *>(partials_dev[k]);
+    }
+    a.n_parts = n_partials;
+    a.out = static_cast<float2 *>(z_out_dev);
+    a.m_first = m_first;
+    a.n_out = n_out;
+    a.conj_sum = p->conj_sum;
+    a.rotate = p->rotate;
+    a.rot_step = p->rot_step;
+    a.rot_base = p->rot_base;
+    a.sc_re = p->out_scale_re;
+    a.sc_im = p->out_scale_im;
+    hipLaunchKernelGGL(k_mfma_combine, dim3(static_cast<unsigned>((n_out + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+    return check_launch("k_mfma_combine");
 }

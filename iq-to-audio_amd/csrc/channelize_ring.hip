@@ -32,6 +32,7 @@
 #define IQA_RING_DMA_AUX 0
 #endif
 
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -42,6 +43,7 @@ typedef __attribute__((address_space(3))) void ring_lds_t;
 constexpr int RG_WAVES = 8;
 
 constexpr int RG_MAX_KS = 16;
+constexpr int RG_ROWS_MAX_KS_C = 11;  // most k steps a pass of the row-staged kernels takes
 constexpr int RG_W = 512;      // sliding window of output sums (positions mod 512), per component
 constexpr int RG_GUARD = 64;   // a tile's scatter reaches at most 59 positions past its lane base: aliases of slots 0..63
 constexpr int RG_AS = RG_W + RG_GUARD;
@@ -407,7 +409,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 // One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
 // stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
 template <int KS, int DBG, bool ACC64, bool ROWS, bool U8>
-__device__ __forceinline__ void ring_block(const MfmaArgs &a)
+__device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_idx)
 {
     using G = RingGeo<KS, ROWS, U8>;
     constexpr int R = G::R, SLOT = G::SLOT;
@@ -422,7 +424,7 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a)
     c.col = c.lane & 31;
     c.h = c.lane >> 5;
 
-    c.i0 = static_cast<long long>(blockIdx.x) * a.range;
+    c.i0 = range_idx * a.range;
     c.cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - c.i0));
     c.m0 = a.m_lo + c.i0;
     c.tiles = (c.cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
@@ -477,7 +479,7 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a)
 template <int KS, int DBG, bool ACC64>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring(MfmaArgs a)
 {
-    ring_block<KS, DBG, ACC64, false, false>(a);
+    ring_block<KS, DBG, ACC64, false, false>(a, blockIdx.x);
 }
 
 // The same block under its own name for short launches (the mixer-sign probes: a few thousand outputs in blocks of
@@ -485,62 +487,167 @@ __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>:
 template <int KS>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_short(MfmaArgs a)
 {
-    ring_block<KS, 0, false, false, false>(a);
+    ring_block<KS, 0, false, false, false>(a, blockIdx.x);
 }
 
 // Row-staged slots (any D, one k-step range per pass), int32 sums.
 template <int KS>
 __global__ __launch_bounds__((RingGeo<KS, true>::THREADS), 3) void k_channelize_mfma_s16_ring_rows(MfmaArgs a)
 {
-    ring_block<KS, 0, false, true, false>(a);
+    ring_block<KS, 0, false, true, false>(a, blockIdx.x);
 }
 
 // Row-staged slots, uint8 I/Q captures (cu8 / RTL-SDR), int32 sums.
 template <int KS>
 __global__ __launch_bounds__((RingGeo<KS, true, true>::THREADS), 3) void k_channelize_mfma_u8_ring_rows(MfmaArgs a)
 {
-    ring_block<KS, 0, false, true, true>(a);
+    ring_block<KS, 0, false, true, true>(a, blockIdx.x);
 }
 
-template <typename K>
-static void ring_launch_kernel(K kernel, int threads, const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool &attr_set)
+
+// ---- several channels of ONE capture in one launch (shared ingest) ---------------------------------------------
+//
+// A lane = one (channel, tap-row group): its own tap fragments, output, scale, rotation.  All lanes of a launch share
+// the capture, the decimation, the k-step range and the output range [m_lo, m_lo + n_out).  The reference runs a whole
+// pipeline per --ft target over the same file (cli.py:683-710); here the lanes of one stretch of the capture run AT THE
+// SAME TIME on the CUs of ONE XCD, so that stretch crosses the fabric once and the other lanes' LDS-DMAs hit in that
+// XCD's L2: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one -- a speed assumption only, nothing
+// here depends on it for correctness), so workgroup b takes lane (b / 8) % n_lanes of output range
+// ((b / 8) / n_lanes) * 8 + b % 8.  Every lane does the same work per tile, so the lanes of a range stay within a few
+// rounds of each other without any synchronisation (4 MiB of L2 per XCD = dozens of rounds of slack).
+struct RingLane {
+    const v4i_t *afrag;
+    float2 *out;
+    const double2 *partial_in;
+    double2 *partial_out;
+    double unit, c_re, c_im;
+    unsigned long long rot_step, rot_base;
+    double rot64_re, rot64_im;
+    float sc_re, sc_im;
+    int col_shift, finalize, conj_sum, rotate;
+};
+
+constexpr int RG_MAX_LANES = 16;  // (<= 5 targets x <= 3 tap-row groups in the reference's CLI; the table travels as kernel arguments)
+
+struct RingMultiArgs {
+    MfmaArgs c;  // what the lanes share; the per-lane fields of `c` are overwritten per workgroup
+    int n_lanes;
+    RingLane lane[RG_MAX_LANES];
+};
+
+template <int KS, bool ROWS, bool U8>
+__device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
 {
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    const int idx = blockIdx.x >> 3;
+    const int li = idx % m.n_lanes;  // uniform: scalar loads from the kernel-argument segment
+    const long long range_idx = static_cast<long long>(idx / m.n_lanes) * 8 + (blockIdx.x & 7);
+    const RingLane &l = m.lane[li];
+    MfmaArgs a = m.c;
+    a.afrag = l.afrag;
+    a.out = l.out;
+    a.partial_in = l.partial_in;
+    a.partial_out = l.partial_out;
+    a.unit = l.unit;
+    a.c_re = l.c_re;
+    a.c_im = l.c_im;
+    a.rot_step = l.rot_step;
+    a.rot_base = l.rot_base;
+    a.rot64_re = l.rot64_re;
+    a.rot64_im = l.rot64_im;
+    a.sc_re = l.sc_re;
+    a.sc_im = l.sc_im;
+    a.col_shift = l.col_shift;
+    a.finalize = l.finalize;
+    a.conj_sum = l.conj_sum;
+    a.rotate = l.rotate;
+    if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
+    ring_block<KS, 0, false, ROWS, U8>(a, range_idx);
+}
+
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_multi(RingMultiArgs m)
+{
+    ring_multi_block<KS, false, false>(m);
+}
+
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, true>::THREADS), 3) void k_channelize_mfma_s16_ring_rows_multi(RingMultiArgs m)
+{
+    ring_multi_block<KS, true, false>(m);
+}
+
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, true, true>::THREADS), 3) void k_channelize_mfma_u8_ring_rows_multi(RingMultiArgs m)
+{
+    ring_multi_block<KS, true, true>(m);
+}
+
+// The 160 KiB dynamic-LDS limit is a per-device attribute of a kernel: `done` remembers (one bit per device id)
+// where it has been raised.  Two threads that race here both set it -- harmless, the call is idempotent.
+template <typename K, typename A>
+static int ring_launch_kernel(K kernel, const char *name, int threads, const A &a, unsigned blocks, size_t lds, hipStream_t stream,
+                              std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_error("%s: cannot raise the dynamic LDS limit on device %d: %s", name, dev, hipGetErrorString(e));
+            return IQA_EHIP;
+        }
+        done.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, a);
+    return check_launch(name);
 }
 
 template <int KS, int DBG, bool ACC64>
-static void ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+static int ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    static bool attr_set = false;
-    ring_launch_kernel(k_channelize_mfma_s16_ring<KS, DBG, ACC64>, RingGeo<KS, false>::THREADS, a, blocks, lds, stream, attr_set);
+    static std::atomic<unsigned long long> done{0};
+    return ring_launch_kernel(k_channelize_mfma_s16_ring<KS, DBG, ACC64>, "k_channelize_mfma_s16_ring", RingGeo<KS, false>::THREADS, a, blocks, lds, stream, done);
 }
 
 template <int KS>
-static void ring_launch_short(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+static int ring_launch_short(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    static bool attr_set = false;
-    ring_launch_kernel(k_channelize_mfma_s16_ring_short<KS>, RingGeo<KS, false>::THREADS, a, blocks, lds, stream, attr_set);
+    static std::atomic<unsigned long long> done{0};
+    return ring_launch_kernel(k_channelize_mfma_s16_ring_short<KS>, "k_channelize_mfma_s16_ring_short", RingGeo<KS, false>::THREADS, a, blocks, lds, stream, done);
 }
 
 template <int KS>
-static void ring_launch_rows(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+static int ring_launch_rows(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    static bool attr_set = false;
-    ring_launch_kernel(k_channelize_mfma_s16_ring_rows<KS>, RingGeo<KS, true>::THREADS, a, blocks, lds, stream, attr_set);
+    static std::atomic<unsigned long long> done{0};
+    return ring_launch_kernel(k_channelize_mfma_s16_ring_rows<KS>, "k_channelize_mfma_s16_ring_rows", RingGeo<KS, true>::THREADS, a, blocks, lds, stream, done);
 }
 
 template <int KS>
-static void ring_launch_rows_u8(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+static int ring_launch_rows_u8(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
-    static bool attr_set = false;
-    ring_launch_kernel(k_channelize_mfma_u8_ring_rows<KS>, RingGeo<KS, true, true>::THREADS, a, blocks, lds, stream, attr_set);
+    static std::atomic<unsigned long long> done{0};
+    return ring_launch_kernel(k_channelize_mfma_u8_ring_rows<KS>, "k_channelize_mfma_u8_ring_rows", RingGeo<KS, true, true>::THREADS, a, blocks, lds, stream, done);
 }
 
-constexpr int RG_ROWS_MAX_KS = 11;  // 8*KS tap registers + the rest must stay within 168 (three waves on two SIMDs)
+template <int KS>
+static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
+{
+    static std::atomic<unsigned long long> done[3] = {{0}, {0}, {0}};
+    if constexpr (KS <= RG_ROWS_MAX_KS_C) {
+        if (u8) return ring_launch_kernel(k_channelize_mfma_u8_ring_rows_multi<KS>, "k_channelize_mfma_u8_ring_rows_multi", RingGeo<KS, true, true>::THREADS, m, blocks, lds, stream, done[2]);
+        if (rows) return ring_launch_kernel(k_channelize_mfma_s16_ring_rows_multi<KS>, "k_channelize_mfma_s16_ring_rows_multi", RingGeo<KS, true>::THREADS, m, blocks, lds, stream, done[1]);
+    } else {
+        if (u8 || rows) {
+            set_error("row-staged ring kernels take at most %d k steps per pass (got %d)", RG_ROWS_MAX_KS_C, KS);
+            return IQA_EINVAL;
+        }
+    }
+    return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[0]);
+}
+
+constexpr int RG_ROWS_MAX_KS = RG_ROWS_MAX_KS_C;  // 8*KS tap registers + the rest must stay within 168 (three waves on two SIMDs)
 
 // 0: the ring kernels do not apply; 1: contiguous slots; 2: row-staged slots (int32 sums only)
 int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64, bool u8)
@@ -577,7 +684,7 @@ size_t mfma_ring_lds_bytes(int ksteps, bool rows, bool u8)
 }
 
 // debug bit 7 (128) selects the 32-bit sums (needs fragments from dsp_plan.plan_mfma(acc32=True))
-void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
+int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
 {
     const int dbg = a.debug & (1 | 16 | 32);
     const bool acc64 = !(a.debug & 128);
@@ -587,8 +694,10 @@ void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_
             RG_ROWS_U8(1); RG_ROWS_U8(2); RG_ROWS_U8(3); RG_ROWS_U8(4); RG_ROWS_U8(5); RG_ROWS_U8(6); RG_ROWS_U8(7); RG_ROWS_U8(8);
             RG_ROWS_U8(9); RG_ROWS_U8(10); RG_ROWS_U8(11);
 #undef RG_ROWS_U8
-            default: return;
+            default: break;
         }
+        set_error("uint8 ring kernel: %d k steps per pass not instantiated (1..%d)", a.ksteps, RG_ROWS_MAX_KS);
+        return IQA_EINVAL;
     }
     if (rows) {
         switch (a.ksteps) {
@@ -596,8 +705,10 @@ void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_
             RG_ROWS(1); RG_ROWS(2); RG_ROWS(3); RG_ROWS(4); RG_ROWS(5); RG_ROWS(6); RG_ROWS(7); RG_ROWS(8);
             RG_ROWS(9); RG_ROWS(10); RG_ROWS(11);
 #undef RG_ROWS
-            default: return;
+            default: break;
         }
+        set_error("row-staged ring kernel: %d k steps per pass not instantiated (1..%d)", a.ksteps, RG_ROWS_MAX_KS);
+        return IQA_EINVAL;
     }
     if (dbg && a.ksteps == 7 && !acc64) {  // diagnostic instantiations exist for the benchmark shape only
         switch (dbg) {
@@ -626,6 +737,57 @@ void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_
 #undef RG_CASE
         default: break;
     }
+    set_error("ring kernel: %d k steps not instantiated (1..%d)", a.ksteps, RG_MAX_KS);
+    return IQA_EINVAL;
+}
+
+// Several lanes (channels x tap-row groups) of one capture in one launch; int32 sums only.  `lanes` holds n_lanes
+// entries whose fields mirror the per-lane part of MfmaArgs; `a` carries what they share.
+int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes, size_t lds, hipStream_t stream, bool rows, bool u8,
+                           unsigned *blocks_out)
+{
+    if (n_lanes < 1 || n_lanes > RG_MAX_LANES) {
+        set_error("a multi-lane launch takes 1..%d lanes (got %d)", RG_MAX_LANES, n_lanes);
+        return IQA_EINVAL;
+    }
+    RingMultiArgs m;
+    m.c = a;
+    m.n_lanes = n_lanes;
+    for (int i = 0; i < n_lanes; ++i) {
+        RingLane &l = m.lane[i];
+        const MfmaLane &s = lanes[i];
+        l.afrag = s.afrag;
+        l.out = s.out;
+        l.partial_in = s.partial_in;
+        l.partial_out = s.partial_out;
+        l.unit = s.unit;
+        l.c_re = s.c_re;
+        l.c_im = s.c_im;
+        l.rot_step = s.rot_step;
+        l.rot_base = s.rot_base;
+        l.rot64_re = s.rot64_re;
+        l.rot64_im = s.rot64_im;
+        l.sc_re = s.sc_re;
+        l.sc_im = s.sc_im;
+        l.col_shift = s.col_shift;
+        l.finalize = s.finalize;
+        l.conj_sum = s.conj_sum;
+        l.rotate = s.rotate;
+    }
+    for (int i = n_lanes; i < RG_MAX_LANES; ++i) m.lane[i] = m.lane[0];
+    const long long ranges = (a.n_out + a.range - 1) / a.range;
+    const long long groups = (ranges + 7) / 8;  // ranges are dealt to the 8 XCD classes: workgroup b -> class b % 8
+    const unsigned blocks = static_cast<unsigned>(groups * n_lanes * 8);
+    if (blocks_out) *blocks_out = blocks;
+    switch (a.ksteps) {
+#define RG_MULTI(K) case K: return ring_launch_multi<K>(m, blocks, lds, stream, rows, u8)
+        RG_MULTI(1); RG_MULTI(2); RG_MULTI(3); RG_MULTI(4); RG_MULTI(5); RG_MULTI(6); RG_MULTI(7); RG_MULTI(8);
+        RG_MULTI(9); RG_MULTI(10); RG_MULTI(11); RG_MULTI(12); RG_MULTI(13); RG_MULTI(14); RG_MULTI(15); RG_MULTI(16);
+#undef RG_MULTI
+        default: break;
+    }
+    set_error("ring kernel: %d k steps not instantiated (1..%d)", a.ksteps, RG_MAX_KS);
+    return IQA_EINVAL;
 }
 
 }  // namespace iqa

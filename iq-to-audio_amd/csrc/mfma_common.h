@@ -78,6 +78,21 @@ __device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, i
 int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64, bool u8);  // 0 none, 1 contiguous, 2 row-staged slots
 bool mfma_ring_supported(int decimation);                                  // mode 1 possible for this decimation
 size_t mfma_ring_lds_bytes(int ksteps, bool rows, bool u8);                // LDS of a block: data ring + window of sums
-void mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds_bytes, hipStream_t stream, bool rows, bool u8);
+int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds_bytes, hipStream_t stream, bool rows, bool u8);  // IQA_* status
+
+// one (channel, tap-row group) of a multi-lane launch: the per-lane part of MfmaArgs
+struct MfmaLane {
+    const v4i_t *afrag;
+    float2 *out;
+    const double2 *partial_in;
+    double2 *partial_out;
+    double unit, c_re, c_im;
+    unsigned long long rot_step, rot_base;
+    double rot64_re, rot64_im;
+    float sc_re, sc_im;
+    int col_shift, finalize, conj_sum, rotate;
+};
+int mfma_ring_launch_multi(const MfmaArgs &common, const MfmaLane *lanes, int n_lanes, size_t lds_bytes, hipStream_t stream, bool rows,
+                           bool u8, unsigned *blocks_out);
 
 }  // namespace iqa

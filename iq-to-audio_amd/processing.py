@@ -21,7 +21,7 @@ import logging
 import math
 import threading
 from collections import OrderedDict
-from ctypes import byref, c_double, c_int32, c_int64
+from ctypes import byref, c_double, c_int32, c_int64, c_void_p
 from dataclasses import dataclass
 from pathlib import Path
 
@@ -504,6 +504,11 @@ class Channelizer:
             halo = None
         z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo, edge_stream)
              if n_out else D.empty(0, "complex64"))
+        self._advance(x, n, last_block)
+        return D.like_input(z, raw)
+
+    def _advance(self, x, n: int, last_block: bool = False) -> None:
+        """Carry the last L-1 raw frames over to the next block and move on by ``n`` frames."""
         keep = 0 if last_block else self.ntaps - 1
         if keep:
             nxt = D.empty(keep * iqio.FRAME_BYTES[self.fmt], "uint8")
@@ -511,7 +516,118 @@ class Channelizer:
                    N.ptr(x), c_int64(n), N.ptr(nxt), N.stream_ptr())
             self._hist = nxt
         self.consumed += n
-        return D.like_input(z, raw)
+
+
+class ChannelBank:
+    """Several channels of ONE capture through a single pass over each block (BASELINE configs 3 and 5).
+
+    The reference runs one whole pipeline per ``--ft`` target over the same file (cli.py:683-710).  Here the channelizers
+    of a capture that share the decimation and the sample format put all their (channel, tap-row group) pairs into ONE
+    launch of the ring kernel (``iqa_channelize_mfma_multi``): the lanes of a stretch of the capture run at the same time
+    on the CUs of one XCD, so the stretch is fetched from HBM once and the other lanes read it from that XCD's L2.
+    Filters with several tap-row groups (ceil(L/D) > 64) are several lanes whose partial sums ``iqa_mfma_combine`` adds
+    up in group order -- the same additions, in the same order, as the chained single-channel passes, so a bank
+    produces exactly what its channelizers would produce one by one.  The few outputs at a block's head and tail go
+    through each channel's float32 kernel as usual.  Falls back to one channel at a time whenever a block is too short
+    for the matrix-core kernels or the channels do not share a kernel shape.
+    """
+
+    MAX_LANES = 16  # per launch (the lane table travels as kernel arguments)
+
+    def __init__(self, channelizers: list):
+        if not channelizers:
+            raise ValueError("a bank needs at least one channelizer")
+        self.chans = list(channelizers)
+        first = self.chans[0]
+        self.fmt, self.decimation = first.fmt, first.decimation
+        for c in self.chans:
+            if (c.fmt, c.decimation, c.consumed) != (self.fmt, self.decimation, first.consumed):
+                raise ValueError("the channels of a bank share the capture: same sample format, decimation and position")
+        self.last_launch = None  # {"lanes": n, "launches": n, "combines": n} of the most recent block (None: one by one)
+
+    def _shared_shape(self) -> bool:
+        ks = [c._kernel for c in self.chans]
+        if len(ks) < 2 or not all(k._mfma_ok and k.mfma_variant == "ring" and k._ring_mode and k.ring_acc32 for k in ks):
+            return False
+        return len({k._ring_mode for k in ks}) == 1
+
+    def process(self, raw, outs=None, last_block: bool = False, halo=None) -> list:
+        """One block of the capture for every channel; returns the decimated streams in channel order."""
+        x, n = _as_frames(raw, self.fmt)
+        outs = list(outs) if outs is not None else [None] * len(self.chans)
+        first = self.chans[0]
+        m_first, n_out = first.outputs_for(n)
+        zs = None
+        if n and n_out and D.is_tensor(raw) and self._shared_shape():
+            zs = self._run_shared(x, n, m_first, n_out, outs, halo)
+        if zs is None:
+            self.last_launch = None
+            return [c.process(raw, out_dev=o, last_block=last_block, halo=halo) for c, o in zip(self.chans, outs)]
+        for c in self.chans:
+            c._advance(x, n, last_block)
+        return zs
+
+    def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo):
+        kernels = [c._kernel for c in self.chans]
+        consumed = self.chans[0].consumed
+        big, big_frames, big_consumed = x, n, consumed
+        if halo is not None:
+            big, lead = halo
+            big_frames, big_consumed = int(big.numel()) // 2, consumed - int(lead)
+        spans = [k._interior(big_consumed, big_frames, m_first, n_out) for k in kernels]
+        m_a, m_b = max(s[0] for s in spans), min(s[1] for s in spans)
+        if any(s[1] <= s[0] for s in spans) or m_b - m_a < _ChannelKernel.mfma_min_outputs:
+            return None
+        n_int = m_b - m_a
+        plans = [k._ensure_mfma() for k in kernels]
+        if len({tuple((ps.k_first, ps.k_count) for ps in mp.passes if ps.group == 0) for mp in plans}) != 1:
+            return None
+        zs = [o if o is not None else D.empty(n_out, "complex64") for o in outs]
+        for c, k, z in zip(self.chans, kernels, zs):  # each channel's own edges (history in front, end of block behind)
+            k._valu(x, n, consumed, c._hist, m_first, m_a - m_first, z)
+            k._valu(x, n, consumed, c._hist, m_b, m_first + n_out - m_b, z[m_b - m_first :])
+            k.last_kernel = ("k_channelize_mfma_u8" if self.fmt == "u8" else "k_channelize_mfma_s16") + "_ring"
+        kranges = [(ps.k_first, ps.k_count) for ps in plans[0].passes if ps.group == 0]
+        ids = [(ci, gi) for ci, mp in enumerate(plans) for gi in range(len(mp.groups))]  # lane identities
+        need_partial = {(ci, gi): (len(kranges) > 1 or len(plans[ci].groups) > 1) for ci, gi in ids}
+        partial = {key: D.empty(2 * n_int, "float64") for key, needed in need_partial.items() if needed}
+        cpx = max(1, _ChannelKernel.launch_blocks // 8)  # CUs per XCD class the launch may fill
+        launches = 0
+        for lo in range(0, len(ids), self.MAX_LANES):
+            part = ids[lo : lo + self.MAX_LANES]
+            ranges = 8 * max(1, cpx // len(part))
+            rng = max(128, -(-(-(-n_int // ranges)) // 32) * 32)
+            for ri, (k_first, k_count) in enumerate(kranges):
+                last_range = ri == len(kranges) - 1
+                table = (N.MfmaLane * len(part))()
+                for lane, (ci, gi) in zip(table, part):
+                    k, mp = kernels[ci], plans[ci]
+                    ps = next(p_ for p_ in mp.passes if p_.group == gi and p_.k_first == k_first)
+                    fin = last_range and len(mp.groups) == 1
+                    buf = partial.get((ci, gi))
+                    lane.afrag_dev = k.afrag_dev[gi][k_first * P.MFMA_KSTEP_BYTES :].data_ptr()
+                    lane.z_out_dev = zs[ci][m_a - m_first :].data_ptr() if fin else None
+                    lane.partial_in_dev = buf.data_ptr() if (buf is not None and ri > 0) else None
+                    lane.partial_out_dev = None if fin else buf.data_ptr()
+                    lane.unit = mp.groups[gi].unit / (256.0 if self.fmt == "u8" else 1.0)
+                    lane.c_re, lane.c_im = ps.c_re, ps.c_im
+                    lane.rot_step, lane.rot_base = k.params.rot_step, k.params.rot_base
+                    lane.out_scale_re, lane.out_scale_im = k.params.out_scale_re, k.params.out_scale_im
+                    lane.q_group, lane.finalize = gi, int(fin)
+                    lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
+                N.call("iqa_channelize_mfma_multi", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first),
+                       c_int32(k_count), c_int32(rng), table, c_int32(len(part)), N.ptr(big), c_int64(big_frames),
+                       c_int64(big_consumed), c_int64(m_a), c_int64(n_int), N.stream_ptr())
+                launches += 1
+        combines = 0
+        for ci, mp in enumerate(plans):
+            if len(mp.groups) > 1:
+                ptrs = (c_void_p * len(mp.groups))(*[partial[(ci, gi)].data_ptr() for gi in range(len(mp.groups))])
+                N.call("iqa_mfma_combine", byref(kernels[ci].params), ptrs, c_int32(len(mp.groups)), c_int64(m_a), c_int64(n_int),
+                       N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
+                combines += 1
+        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines)
+        return zs
 
 
 def _mean_power_into(z_dev, skip: int, out_slot) -> None:
@@ -964,20 +1080,24 @@ class _Target:
         self.z_all = D.empty(n_dec_total, "complex64") if (self.pass_through or self.cfg.dump_iq_path) else None
         self.audio_all = None if self.pass_through else D.empty(n_dec_total, "float32")
 
-    def process(self, raw, done: int, n: int, chunk: int, tracker) -> None:
+    def before_block(self, done: int, n: int, chunk: int) -> None:
+        """Upload what the demodulator needs for the block of ``n`` frames at frame ``done`` ahead of the channelizer."""
         _, n_out = self.chan.outputs_for(n)
-        starts = None
+        self._starts = None
         if self.demod is not None and n_out:
-            starts = P.chunk_output_starts(chunk, self.decimation, done, n)
-            self.demod.prepare(n_out, starts)
-        z = self.chan.process(raw)
+            self._starts = P.chunk_output_starts(chunk, self.decimation, done, n)
+            self.demod.prepare(n_out, self._starts)
+
+    def after_block(self, z, tracker) -> None:
+        """The block's decimated stream ``z`` -> dump / slice buffers, demodulator, progress."""
+        n_out = int(z.numel())
         tracker.advance("channel", float(n_out))
         if self.z_all is not None and n_out:
             self.z_all[self.pos_dec : self.pos_dec + n_out] = z
             if self.cfg.dump_iq_path:
                 tracker.advance("dump_iq", float(n_out))
         if self.demod is not None and n_out:
-            self.demod.process(z, starts, self.audio_all[self.pos_dec : self.pos_dec + n_out])
+            self.demod.process(z, self._starts, self.audio_all[self.pos_dec : self.pos_dec + n_out])
         tracker.advance("demod", float(n_out))
         tracker.advance("encode", n_out / max(self.fs_channel, 1e-9) * 48_000.0)
         self.pos_dec += n_out
@@ -1013,8 +1133,9 @@ class MultiChannelPipeline:
     """Several target frequencies of ONE capture in a single pass over the file.
 
     The reference CLI runs a whole pipeline per ``--ft`` target, re-decoding the input each time
-    (cli.py:683-710).  Here every block of the capture is staged and uploaded once and all channels
-    are extracted from the HBM-resident block (BASELINE configs 3/5); each channel keeps exactly the
+    (cli.py:683-710).  Here every block of the capture is staged and uploaded once, and the channels that share a
+    decimation are extracted by ONE launch of the channelizer over the HBM-resident block (:class:`ChannelBank`: every
+    (channel, tap-row group) is a lane of the ring kernel; BASELINE configs 3/5); each channel keeps exactly the
     per-target semantics of :class:`ProcessingPipeline` (own mixer-sign probe, taps, decoder, output).
     ``configs`` must agree on the input file and its interpretation.
     """
@@ -1135,6 +1256,13 @@ class MultiChannelPipeline:
                 return [ProcessingResult(rate_probe, center_freq, t.target_freq, t.freq_offset, t.decimation, t.fs_channel,
                                          t.mix_sign, 0.0) for t in targets]
 
+            # channels that share a decimation share their pass over every block (ChannelBank); built after settle(),
+            # which may have replaced a channelizer by the one for the other mixer sign
+            banks = []
+            for dec in sorted({t.decimation for t in targets}):
+                members = [t for t in targets if t.decimation == dec]
+                banks.append((ChannelBank([t.chan for t in members]), members))
+            self.banks = [b for b, _ in banks]
             done = 0
             while done < total:
                 _check_cancel(f"block at frame {done}")
@@ -1145,8 +1273,11 @@ class MultiChannelPipeline:
                 n = hi - done
                 tracker.advance("ingest", float(n))
                 tracker.status(f"channel @ {done}")
-                for t in targets:
-                    t.process(raw, done, n, chunk, tracker)
+                for bank, members in banks:  # one pass over the block per decimation, all its channels at once
+                    for t in members:
+                        t.before_block(done, n, chunk)
+                    for t, z in zip(members, bank.process(raw)):
+                        t.after_block(z, tracker)
                 _check_cancel("encode")
                 done = hi
 

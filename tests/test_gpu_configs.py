@@ -333,3 +333,63 @@ def test_config5_unit_five_nfm_channels(A, tmp_path):
         assert np.max(np.abs(pcm.astype(np.int32) - own48.astype(np.int32))) <= 1
         assert rms(pcm.astype(np.float64) / 32768.0 - ref48) < 1e-4 + (1.0 if problems else 0.0)
     assert not problems, problems
+
+
+# ---- shared ingest: several channels in one launch ------------------------------------------------
+
+
+@pytest.mark.parametrize("fs,fmt,specs,n", [
+    # C3: D = 208, contiguous slots, 1 + 2 + 3 + 3 + 1 tap-row groups = 10 lanes, three filters finished by the combine kernel
+    (20e6, "s16", [(25e3, 12_500.0, 1), (-150e3, 10_000.0, 1), (400e3, 2_800.0, 1), (-1.1e6, 2_800.0, -1), (2.3e6, 12_500.0, 1)], 12_000_000),
+    # C2 rate: D = 104 (loader waves), three single-group lanes
+    (10e6, "s16", [(25e3, 12_500.0, 1), (-1.3e6, 12_500.0, 1), (3.1e6, 12_500.0, -1)], 7_000_000),
+    # C5's unit: D = 521, row-staged slots, five channels x three k-step passes chained through partial sums
+    (50e6, "s16", [(-1.95e6, 12_500.0, 1), (-1.85e6, 12_500.0, 1), (-50e3, 12_500.0, 1), (50e3, 12_500.0, -1), (1.95e6, 12_500.0, 1)], 22_000_000),
+    # uint8 capture, odd decimation (RTL-SDR rate)
+    (2.4e6, "u8", [(25e3, 12_500.0, 1), (-300e3, 12_500.0, 1)], 5_000_000),
+])
+def test_channel_bank_is_bit_identical_to_one_channel_at_a_time(A, fs, fmt, specs, n):
+    """ChannelBank (one launch of the ring kernel for all channels of a capture, iqa_channelize_mfma_multi +
+    iqa_mfma_combine) against the same channelizers run one by one: the same integers are added in the same order, so
+    the decimated streams must be EQUAL bit for bit -- over two ragged blocks (history, decimator phase) and with
+    mixed mixer signs.  One channel is also held against the oracle so that the pair is not jointly wrong."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd import processing as PR
+
+    d, _ = P.choose_decimation(fs, 96_000.0)
+    s16 = O.synth_capture_s16(fs, n / fs, specs[0][0], seed=3).reshape(-1)
+    raw = s16 if fmt == "s16" else ((s16.astype(np.int32) >> 8) + 128).astype(np.uint8)
+    x = D.to_device(raw, "int16" if fmt == "s16" else "uint8")
+    cut = 2 * (n // 2 + 12_345)
+    old_min = PR._ChannelKernel.mfma_min_outputs
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 4096
+
+        def make():
+            return [A.Channelizer(A.design_channel_filter(fs, bw, d), sample_rate=fs, freq_offset=off, mix_sign=sign, decimation=d, fmt=fmt)
+                    for off, bw, sign in specs]
+
+        singles = [torch.cat([c.process(x[:cut]), c.process(x[cut:])]) for c in make()]
+        bank = A.ChannelBank(make())
+        first = bank.process(x[:cut])
+        info = dict(bank.last_launch)
+        banked = [torch.cat([a_, b_]) for a_, b_ in zip(first, bank.process(x[cut:]))]
+    finally:
+        PR._ChannelKernel.mfma_min_outputs = old_min
+    groups = [max(1, -(-(-(-len(A.design_channel_filter(fs, bw, d)) // d)) // 64)) for _, bw, _ in specs]
+    kranges = 1 if (d % 4 == 0 and d <= 256 and fmt == "s16") else -(-(-(-2 * d // 32)) // 11)
+    assert info == dict(lanes=sum(groups), launches=kranges, combines=sum(g > 1 for g in groups)), info
+    for i, (one, many) in enumerate(zip(singles, banked)):
+        assert one.numel() == many.numel() == -(-n // d)
+        assert torch.equal(one, many), (i, float((one - many).abs().max()))
+    off, bw, sign = specs[0]
+    n_cpu = min(n, 1_500_000)
+    taps = A.design_channel_filter(fs, bw, d)
+    want = O.decimate(O.overlap_save(O.nco_mix(O.ingest_to_complex64(raw[: 2 * n_cpu], fmt), O.NcoState(off, fs), sign),
+                                     O.OverlapSaveState(taps, 65536)), O.DecimState(d))
+    got = banked[0].cpu().numpy()[: want.size]
+    assert rms(got - want) < 1.4e-5 * max(1.0, float(np.sqrt(len(taps) / 6401.0)))
+    assert rms(want) > 0.05
