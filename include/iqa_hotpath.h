@@ -20,7 +20,10 @@
  *     else -> RuntimeError, as the reference raises them.
  *   - Streaming state (FIR history, discriminator previous sample, IIR states, peak)
  *     lives in small caller-owned device buffers whose layouts are given below, so
- *     the library has no globals and is re-entrant per stream.
+ *     the library keeps no per-stream or per-capture state and is re-entrant per stream and
+ *     per host thread.  What it does keep, process-wide and thread-safe: one bit per
+ *     (kernel, device id) "dynamic-LDS limit raised" (atomics), and the spectrum entry point's
+ *     LRU of rocFFT plans keyed by (device, nfft, batch) behind a mutex.
  */
 #ifndef IQA_HOTPATH_H
 #define IQA_HOTPATH_H

@@ -22,8 +22,9 @@
 //     block is not bounded by LDS: every CU gets ONE contiguous range of the launch (persistent blocks:
 //     one prologue per CU, 63 rows of halo per CU).
 //
-// A contiguous slot is 2048*KS bytes >= 31 rows + one K-padded row (KS = ceil(2D/32) k steps), so an issuing wave
-// issues exactly KS DMAs per round; it needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
+// A contiguous slot is 1024*(2*KS + 1) bytes >= 32 rows at a pitch of D/4 (+1) 16-byte units (KS = ceil(2D/32) k steps;
+// the K padding of the last k step reads on into the next row, against zero taps); a tile takes 2*KS + 1 DMA
+// instructions; it needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
 // Every other decimation (odd D, D > 256 in several k-step ranges) uses row-staged slots, see RingGeo.
 #include "mfma_common.h"
 
@@ -60,8 +61,15 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 }
 
 // Two ways a tile (32 data rows) sits in a ring slot:
-//   contiguous (ROWS = false): the 32*D frames exactly as they lie in the capture, 2*KS chunks of 1 KiB -- needs
-//     16-byte aligned rows (D % 4 == 0) and all k steps of a row in one pass (KS <= 16);
+//   contiguous (ROWS = false): the 32*D frames of the tile, one contiguous run of the capture, fetched by 2*KS + 1
+//     DMA instructions of 1 KiB (64 lanes x 16 bytes) -- needs 16-byte aligned rows (D % 4 == 0) and all k steps of a
+//     row in one pass (KS <= 16).  In LDS the rows sit at a pitch of an ODD number of 16-byte units (the row's own D/4
+//     units, plus one of padding when that is even): the fragment reads of a wave -- ds_read_b128, lane = row, served
+//     in four groups of 16 lanes -- then touch 16 different bank quads per group.  At the capture's own pitch they are
+//     2-way conflicts at D = 104 and 4-way at D = 208 (16 LDS cycles per wave-instruction instead of 4: with 26 of them
+//     per wave and tile the LDS, not the matrix pipe, bounded a CU as soon as the data came from L2).  An LDS-DMA lane
+//     writes to (instruction base + 16 * lane) but fetches from any address, so the padding costs nothing but the
+//     per-lane source offsets (`ring_src_off`, computed once per workgroup);
 //   row-staged (ROWS = true): row j's k-step range of THIS pass, 64*KS bytes, at a pitch of 64*KS + 16 bytes (16 bytes
 //     of padding: rows 4 banks apart, conflict-free reads), one DMA per row with 4*KS active lanes.  Any D, and the
 //     k-step ranges of a long row (D = 521: 33 k steps in three passes of 11) each fetch only their own third of every
@@ -73,9 +81,11 @@ struct RingGeo {
     static_assert(ROWS || !U8, "uint8 captures use row-staged slots");
     static constexpr int KBYTES = U8 ? 32 : 64;  // bytes of a row per k step
     static constexpr int PITCH = KBYTES * KS + 16;
-    static constexpr int SLOT = ROWS ? 32 * PITCH : 2048 * KS;
+    static constexpr bool PADDED = KS <= 13;  // contiguous slots: rows at an odd pitch in LDS (conflict-free fragment reads)
+    static constexpr int NI = 2 * KS + 1;  // contiguous slots: 1 KiB DMA instructions per tile (32 rows at a padded pitch)
+    static constexpr int SLOT = ROWS ? 32 * PITCH : 1024 * NI;
     static constexpr bool LOADERS = ROWS || KS <= 8;  // two extra waves feed the ring and emit (needs <= 168 registers)
-    static constexpr int NDMA = ROWS ? 32 : (LOADERS ? 2 * KS : KS);  // DMAs per issuing wave and round
+    static constexpr int NDMA = ROWS ? 32 : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
     static constexpr int FIT = (160 * 1024 - RG_ACC_BYTES) / (2 * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
     static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
@@ -89,10 +99,26 @@ struct RingCtx {
     char *smem;
     int *s_acc;           // [Sre | Sim], RG_AS entries each, output position p at slot p mod RG_W.  ACC64: one int64
                           // S1*2^32 + S2 per entry (16-bit taps, exact); else one int32 256*S1 + S2 (~14-bit taps)
-    const char *stream0;  // this lane's source byte of chunk (rt & 1) of tile 0
+    const char *stream0;  // row-staged slots: this lane's source byte of row 0 of tile 0; contiguous: tile 0's first byte
     long long tile_bytes, i0, m0;
     int tiles, rounds, cnt, lane_off, rt, cp, col, h, lane;
+    int row_units, pitch_units;  // contiguous slots: 16-byte units per data row in the capture / in LDS (odd)
 };
+
+// Source offset (bytes from the tile's first byte) of the 16 bytes lane `lane` of DMA instruction `idx` fetches: the
+// instruction fills LDS units 64*idx .. 64*idx + 63 of the slot, unit q holds unit q % pitch of row q / pitch; the
+// padding unit of a row and the units behind row 31 re-fetch a neighbour (they are read, if at all, against zero taps).
+__device__ __forceinline__ int ring_src_off(int idx, int lane, int row_units, int pitch_units)
+{
+    const int q = 64 * idx + lane;
+    int r = q / pitch_units;
+    int u = q - r * pitch_units;
+    if (r > 31) {
+        r = 31;
+        u = row_units - 1;
+    }
+    return (r * row_units + min(u, row_units - 1)) * 16;
+}
 
 // Emission state of the emitting wave: lane l owns position 64 k + 1 + l of group k; its rotation advances by
 // the host-computed step of 64 outputs per group (float64 recurrence, ~1e-16 per step).
@@ -187,6 +213,11 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
     constexpr int R = G::R, SLOT = G::SLOT;
     constexpr bool STREAM = !(DBG & 16);
     const int cp = c.cp;
+    int soff[ROWS ? 1 : G::NI];
+    if constexpr (!ROWS) {
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) soff[i] = ring_src_off(i, c.lane, c.row_units, c.pitch_units);
+    }
     auto issue_tile = [&](int tile, int slot) {
         const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
         char *dst = c.smem + (slot * 2 + cp) * SLOT;
@@ -200,8 +231,8 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2 * KS; ++i)
-                __builtin_amdgcn_global_load_lds(src + i * 1024, (ring_lds_t *)(dst + i * 1024), 16, 0, IQA_RING_DMA_AUX);
+            for (int i = 0; i < G::NI; ++i)
+                __builtin_amdgcn_global_load_lds(src + soff[i], (ring_lds_t *)(dst + i * 1024), 16, 0, IQA_RING_DMA_AUX);
         }
     };
     if (STREAM) {
@@ -252,16 +283,35 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     static_assert(!(ROWS && ISSUER), "row-staged slots are always fed by loader waves");
     constexpr bool STREAM = ISSUER && !(DBG & 16);
     const int rt = c.rt, cp = c.cp;
-    auto issue = [&](int tile, int slot, int i) {
-        const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes + i * 2048;
-        char *dst = c.smem + (slot * 2 + cp) * SLOT + (rt & 1) * 1024 + i * 2048;
-        __builtin_amdgcn_global_load_lds(src, (ring_lds_t *)dst, 16, 0, IQA_RING_DMA_AUX);
+    // the two issuing waves of a parity share the tile's 2*KS + 1 DMA instructions: wave p = rt & 1 issues numbers
+    // p, p + 2, ...; both issue KS + 1 (the counted s_waitcnt wants one number for both), so the odd wave's last one
+    // repeats the even wave's last (same bytes to the same place)
+    // Source offsets of this wave's KS + 1 instructions: a table in registers where the rows are padded (G::PADDED);
+    // the longest rows (KS >= 14, already at the 256-register limit -- a spill would put scratch loads into the vmcnt
+    // sequence the counted waits rely on) keep the capture's own pitch: unit q of the slot is unit q of the tile.
+    int soff[(ISSUER && G::PADDED) ? KS + 1 : 1];
+    if constexpr (ISSUER && G::PADDED) {
+#pragma unroll
+        for (int i = 0; i <= KS; ++i) soff[i] = ring_src_off(min(2 * i + (rt & 1), 2 * KS), c.lane, c.row_units, c.pitch_units);
+    } else {
+        soff[0] = c.lane * 16;
+    }
+    const int odd_kib = (rt & 1) * 1024;
+    auto issue = [&](int tile, int slot, int i) {  // `i` is a compile-time constant at every call site
+        const char *tile0 = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
+        char *slot0 = c.smem + (slot * 2 + cp) * SLOT;
+        const int at = (i < KS) ? odd_kib + i * 2048 : 2 * KS * 1024;  // instruction numbers p, p + 2, ..., then 2*KS
+        if constexpr (ISSUER && G::PADDED) {
+            __builtin_amdgcn_global_load_lds(tile0 + soff[i], (ring_lds_t *)(slot0 + at), 16, 0, IQA_RING_DMA_AUX);
+        } else {
+            __builtin_amdgcn_global_load_lds(tile0 + soff[0] + at, (ring_lds_t *)(slot0 + at), 16, 0, IQA_RING_DMA_AUX);
+        }
     };
     if (STREAM) {
 #pragma unroll
         for (int rr = 0; rr < R - 1; ++rr)
 #pragma unroll
-            for (int i = 0; i < KS; ++i) issue(2 * rr + cp, rr, i);
+            for (int i = 0; i <= KS; ++i) issue(2 * rr + cp, rr, i);
     }
     RingEmit em{1.0, 0.0};
     if (EMIT && a.finalize && a.rotate) {
@@ -377,6 +427,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (PF) issue(pf_tile, pf_slot, KS);
                 }
                 if (DBG & 32) acc1 = acc2 = zero16;
                 if (DBG & 1) {
@@ -393,7 +444,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             else tile_body(std::false_type{});
         } else if (pf) {
 #pragma unroll
-            for (int i = 0; i < KS; ++i) issue(pf_tile, pf_slot, i);
+            for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
@@ -438,8 +489,10 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     const long long row_bytes = static_cast<long long>(FB) * a.D;
     c.tile_bytes = 32 * row_bytes;
     const char *stream = reinterpret_cast<const char *>(a.raw) + FB * ((c.m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
-                         c.lane * 16 + (ROWS ? G::KBYTES * a.k_first : 0);
-    c.lane_off = c.col * (ROWS ? G::PITCH : static_cast<int>(row_bytes)) + (G::KBYTES / 2) * c.h;
+                         (ROWS ? c.lane * 16 + G::KBYTES * a.k_first : 0);
+    c.row_units = static_cast<int>(row_bytes >> 4);
+    c.pitch_units = G::PADDED ? (c.row_units | 1) : c.row_units;  // odd: conflict-free fragment reads (see RingGeo)
+    c.lane_off = c.col * (ROWS ? G::PITCH : 16 * c.pitch_units) + (G::KBYTES / 2) * c.h;
 
     if (LOADERS && wave >= RG_WAVES) {
         c.cp = wave - RG_WAVES;
@@ -461,7 +514,7 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
         for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(fq[ks][0]), "v"(fq[ks][1]));
     }
     __syncthreads();
-    c.stream0 = stream + (c.rt & 1) * 1024;
+    c.stream0 = stream;
     if constexpr (LOADERS) {
         if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true>(a, c, fq);
         else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false>(a, c, fq);
@@ -653,7 +706,8 @@ constexpr int RG_ROWS_MAX_KS = RG_ROWS_MAX_KS_C;  // 8*KS tap registers + the re
 int mfma_ring_mode(int decimation, int k_first, int k_count, bool acc64, bool u8)
 {
     const int ks_all = (2 * decimation + 31) / 32;
-    if (!u8 && decimation >= 4 && (decimation & 3) == 0 && ks_all <= RG_MAX_KS && k_first == 0 && k_count == ks_all) return 1;
+    // (64-bit sums at 16 k steps do not fit 256 registers: a spill's scratch loads would join the counted vmcnt sequence)
+    if (!u8 && decimation >= 4 && (decimation & 3) == 0 && ks_all <= (acc64 ? RG_MAX_KS - 1 : RG_MAX_KS) && k_first == 0 && k_count == ks_all) return 1;
     if (!acc64 && decimation >= 1 && k_count >= 1 && k_count <= RG_ROWS_MAX_KS && k_first >= 0 && k_first + k_count <= ks_all) return 2;
     return 0;
 }

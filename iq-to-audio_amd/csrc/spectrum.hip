@@ -8,13 +8,14 @@
 //   psd_db[f][k] = 10 log10( |X[k']|^2 / scale + 1e-18 ),  k' = (k + nfft/2) mod nfft      (fftshift, :161/:37)
 //
 // The FFT is rocFFT's (through hipFFT, double complex, batched, in place); windowing + ingest conversion and the
-// |.|^2 / log / fftshift epilogue are the two kernels around it.  Plans are cached per (nfft, batch) -- the only
-// state the library keeps besides the thread-local error string; calls that share a plan are serialised by its stream.
+// |.|^2 / log / fftshift epilogue are the two kernels around it.  Plans are cached per (device, nfft, batch) in a small
+// LRU behind a mutex -- beside the per-kernel "LDS limit raised on device d" bits and the thread-local error string the
+// only state the library keeps; the mutex is held while a plan's stream is set and its FFT enqueued.
 #include "common.h"
 
 #include <hipfft/hipfft.h>
 
-#include <map>
+#include <list>
 #include <mutex>
 #include <utility>
 
@@ -95,9 +96,18 @@ __global__ __launch_bounds__(256) void k_pair_average(const float *in, int n_row
     out[static_cast<long long>(r) * n_cols + c] = v;
 }
 
+// rocFFT plans are expensive (milliseconds) and bound to the device they were made on: a small LRU keyed by
+// (device, nfft, batch).  A plan carries its stream, so the lock is held from hipfftSetStream to the end of
+// hipfftExec* (both are host-side enqueues; the FFT itself runs asynchronously on the caller's stream).  Evicted
+// plans are destroyed.
 struct PlanCache {
+    static constexpr size_t kMax = 8;
+    struct Entry {
+        int dev, nfft, batch;
+        hipfftHandle handle;
+    };
     std::mutex mu;
-    std::map<std::pair<int, int>, hipfftHandle> plans;
+    std::list<Entry> lru;  // front = most recently used
 };
 static PlanCache &plan_cache()
 {
@@ -105,14 +115,17 @@ static PlanCache &plan_cache()
     return c;
 }
 
-static int get_plan(int nfft, int batch, hipfftHandle *out)
+// with c.mu held
+static int get_plan_locked(PlanCache &c, int nfft, int batch, hipfftHandle *out)
 {
-    PlanCache &c = plan_cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    auto it = c.plans.find({nfft, batch});
-    if (it != c.plans.end()) {
-        *out = it->second;
-        return IQA_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (auto it = c.lru.begin(); it != c.lru.end(); ++it) {
+        if (it->dev == dev && it->nfft == nfft && it->batch == batch) {
+            c.lru.splice(c.lru.begin(), c.lru, it);
+            *out = c.lru.front().handle;
+            return IQA_OK;
+        }
     }
     hipfftHandle h;
     int n[1] = {nfft};
@@ -121,7 +134,11 @@ static int get_plan(int nfft, int batch, hipfftHandle *out)
         set_error("hipfftPlanMany(nfft=%d, batch=%d) failed: %d", nfft, batch, static_cast<int>(r));
         return IQA_EHIP;
     }
-    c.plans[{nfft, batch}] = h;
+    c.lru.push_front({dev, nfft, batch, h});
+    while (c.lru.size() > PlanCache::kMax) {
+        (void)hipfftDestroy(c.lru.back().handle);  // (its last FFT was enqueued under this lock; rocFFT keeps what it needs)
+        c.lru.pop_back();
+    }
     *out = h;
     return IQA_OK;
 }
@@ -143,13 +160,6 @@ extern "C" int iqa_psd_frames(int32_t fmt, int32_t iq_order, const void *samples
     if (!samples_dev || !window_dev || !work_dev) return fail_inval("NULL device pointer");
     if (!(scale > 0.0)) return fail_inval("scale must be positive");
     hipStream_t s = as_stream(stream);
-    hipfftHandle plan;
-    const int rc = get_plan(nfft, n_frames, &plan);
-    if (rc != IQA_OK) return rc;
-    if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
-        set_error("hipfftSetStream failed");
-        return IQA_EHIP;
-    }
     const dim3 grid((nfft + 255) / 256, n_frames), block(256);
     double2 *work = static_cast<double2 *>(work_dev);
     const double *win = static_cast<const double *>(window_dev);
@@ -165,10 +175,21 @@ extern "C" int iqa_psd_frames(int32_t fmt, int32_t iq_order, const void *samples
             break;
     }
     if (check_launch("k_psd_window") != IQA_OK) return IQA_EHIP;
-    if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex *>(work), reinterpret_cast<hipfftDoubleComplex *>(work),
-                      HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
-        set_error("hipfftExecZ2Z failed");
-        return IQA_EHIP;
+    {
+        PlanCache &cache = plan_cache();
+        std::lock_guard<std::mutex> lock(cache.mu);
+        hipfftHandle plan;
+        const int rc = get_plan_locked(cache, nfft, n_frames, &plan);
+        if (rc != IQA_OK) return rc;
+        if (hipfftSetStream(plan, s) != HIPFFT_SUCCESS) {
+            set_error("hipfftSetStream failed");
+            return IQA_EHIP;
+        }
+        if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex *>(work), reinterpret_cast<hipfftDoubleComplex *>(work),
+                          HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+            set_error("hipfftExecZ2Z failed");
+            return IQA_EHIP;
+        }
     }
     hipLaunchKernelGGL(k_psd_finish, dim3((nfft + 255) / 256), block, 0, s, work, (int)nfft, (int)n_frames, 1.0 / scale,
                        static_cast<double *>(psd_db_dev), static_cast<float *>(psd_db_f32_dev), static_cast<double *>(sum_db_dev));

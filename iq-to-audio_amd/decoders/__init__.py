@@ -1,25 +1,29 @@
-"""Pluggable demodulators (same factory contract as the reference's ``decoders/__init__.py``)."""
+"""Pluggable demodulators on the HIP library (the reference's ``decoders`` package)."""
 from __future__ import annotations
 
 from .am import AMDecoder
-from .base import Decoder, DecoderStats
+from .base import Decoder, DecoderStats, GpuDecoder
 from .nfm import NarrowbandFMDecoder
 from .ssb import SSBDecoder
 
+# mode string -> how to build its decoder from (deemph_us, agc_enabled); the AGC switch only reaches the SSB decoder
+_BUILDERS = {
+    "nfm": lambda deemph_us, agc: NarrowbandFMDecoder(deemph_us=deemph_us),
+    "am": lambda deemph_us, agc: AMDecoder(),
+    "usb": lambda deemph_us, agc: SSBDecoder(sideband="usb", agc_enabled=agc),
+    "lsb": lambda deemph_us, agc: SSBDecoder(sideband="lsb", agc_enabled=agc),
+}
+_ALIASES = {"fm": "nfm", "ssb": "usb"}
+
 
 def create_decoder(mode: str, *, deemph_us: float, agc_enabled: bool) -> Decoder:
-    """nfm/fm -> NFM (agc ignored); am -> AM (agc ignored); usb/ssb, lsb -> SSB.
-    Anything else raises ValueError (reference decoders/__init__.py:9-24)."""
-    mode = mode.lower()
-    if mode in {"nfm", "fm"}:
-        return NarrowbandFMDecoder(deemph_us=deemph_us)
-    if mode == "am":
-        return AMDecoder()
-    if mode in {"usb", "ssb"}:
-        return SSBDecoder(sideband="usb", agc_enabled=agc_enabled)
-    if mode == "lsb":
-        return SSBDecoder(sideband="lsb", agc_enabled=agc_enabled)
-    raise ValueError(f"Unsupported demod mode '{mode}'.")
+    """The decoder for a ``--demod`` mode (reference decoders/__init__.py:9-24): nfm | fm, am, usb | ssb, lsb;
+    anything else is a ``ValueError``."""
+    key = mode.lower()
+    build = _BUILDERS.get(_ALIASES.get(key, key))
+    if build is None:
+        raise ValueError(f"Unsupported demod mode '{key}'.")
+    return build(deemph_us, agc_enabled)
 
 
-__all__ = ["Decoder", "DecoderStats", "create_decoder", "NarrowbandFMDecoder", "AMDecoder", "SSBDecoder"]
+__all__ = ["Decoder", "DecoderStats", "GpuDecoder", "create_decoder", "NarrowbandFMDecoder", "AMDecoder", "SSBDecoder"]

@@ -1,48 +1,26 @@
-"""AM: envelope detector + DC blocker (reference decoders/am.py), on the HIP library."""
+"""AM: envelope, then the DC blocker (reference decoders/am.py:11-50) -- no AGC, no normalisation."""
 from __future__ import annotations
 
 from ctypes import c_int64
 
 from .. import _dev as D
 from .. import _native as N
-from .base import Decoder, DecoderStats
-from .common import DCBlocker, rms_dbfs_of
+from .base import GpuDecoder
+from .common import DCBlocker
 
 
-class AMDecoder(Decoder):
-    """|z| then y[n] = x[n]-x[n-1]+r*y[n-1]; no AGC, no normalisation (reference decoders/am.py:11-50)."""
-
+class AMDecoder(GpuDecoder):
     name = "am"
 
     def __init__(self, dc_radius: float = 0.995):
-        self._dc_blocker = DCBlocker(radius=dc_radius)
-        self._last_stats = None
-        self._intermediates = {}
-        self._sample_rate = 0.0
+        super().__init__()
+        self.dc = DCBlocker(radius=dc_radius)
 
-    def setup(self, sample_rate: float) -> None:
-        self._sample_rate = sample_rate
+    def stages(self, z) -> list:
+        mag = D.empty(z.numel(), "float32")
+        N.call("iqa_envelope", N.ptr(z), c_int64(z.numel()), N.ptr(mag), N.stream_ptr())
+        return [("envelope", mag), ("dc_block", self.dc.process(mag))]
 
-    def process(self, samples):
-        if self._sample_rate == 0.0:
-            raise RuntimeError("Decoder.setup(sample_rate) must be called before processing data.")
-        z = D.to_device(samples, "complex64")
-        envelope = D.empty(z.numel(), "float32")
-        N.call("iqa_envelope", N.ptr(z), c_int64(z.numel()), N.ptr(envelope), N.stream_ptr())
-        ac_coupled = self._dc_blocker.process(envelope)
-        stats = DecoderStats(rms_dbfs=rms_dbfs_of(ac_coupled))
-        self._last_stats = stats
-        if z.numel():
-            self._intermediates = {"envelope": (envelope, self._sample_rate), "dc_block": (ac_coupled, self._sample_rate),
-                                   "audio": (ac_coupled, self._sample_rate)}
-        return D.like_input(ac_coupled, samples), stats
-
-    def finalize(self) -> None:
-        return
-
-    def intermediates(self) -> dict:
-        return {k: (v.cpu().numpy().copy(), r) for k, (v, r) in self._intermediates.items()}
-
-    @property
-    def last_stats(self):
-        return self._last_stats
+    def fused_params(self) -> N.DemodParams:
+        return N.DemodParams(mode=N.DEMOD_MODE["am"], agc_enabled=0, deemph_alpha=0.0, dc_radius=self.dc.radius,
+                             agc_target=0.0, agc_decay=0.0)

@@ -22,25 +22,27 @@ FMT_CODE = {"s16": 0, "u8": 1, "f32": 2}
 FMT_NUMPY = {"s16": np.int16, "u8": np.uint8, "f32": np.float32}
 
 
+#: (minimum sample rate, seconds of signal a chunk should hold), highest rate first -- reference processing.py:69-72
+_CHUNK_SECONDS = ((5_000_000.0, 0.50), (2_000_000.0, 0.40), (0.0, 0.25))
+
+
 def tune_chunk_size(sample_rate: float, requested: int) -> int:
-    """Effective chunk length (reference processing.py:65-81).
+    """Effective chunk length (reference processing.py:65-81): the requested one unless the rate calls for more --
+    then the next power of two holding 0.25 s of signal (0.40 s from 2 MS/s, 0.50 s from 5 MS/s), never below the
+    request and never above 4 Mi frames.
 
     The result is *semantic*, not a memory knob here: it fixes where the SSB AGC gain
     restarts and which prefix ``choose_mix_sign`` inspects.
     """
-    base = max(1, requested)
+    floor = max(1, requested)
     if sample_rate <= 0:
-        return base
-    target_seconds = 0.25
-    if sample_rate >= 2_000_000.0:
-        target_seconds = 0.40
-    if sample_rate >= 5_000_000.0:
-        target_seconds = 0.50
-    desired = int(round(sample_rate * target_seconds))
-    if desired <= base:
-        return base
-    desired = min(MAX_CHUNK, max(base, desired))
-    return int(min(max(1 << math.ceil(math.log2(desired)), base), MAX_CHUNK))
+        return floor
+    seconds = next(s for rate, s in _CHUNK_SECONDS if sample_rate >= rate)
+    wanted = int(round(sample_rate * seconds))
+    if wanted <= floor:
+        return floor
+    wanted = min(wanted, MAX_CHUNK)
+    return int(min(max(1 << (wanted - 1).bit_length(), floor), MAX_CHUNK))
 
 
 def choose_decimation(sample_rate: float, fs_ch_target: float) -> tuple[int, float]:

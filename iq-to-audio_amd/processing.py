@@ -421,6 +421,14 @@ class OverlapSaveFIR:
             return np.zeros(self.overlap, dtype=np.complex64)
         return self._hist.cpu().numpy()
 
+    @property
+    def taps_fft(self) -> np.ndarray:
+        """The reference's frequency response of the zero-padded taps (processing.py:317-321), computed on request:
+        nothing here uses it (the filter runs in the time domain), it exists for callers that inspect the stage."""
+        padded = np.zeros(self.fft_size, dtype=np.complex128)
+        padded[: self.filter_len] = self.taps
+        return np.fft.fft(padded)
+
     def process(self, samples):
         if _size(samples) == 0:
             return samples
@@ -802,17 +810,8 @@ class ChannelDemod:
     def __init__(self, mode: str, fs_channel: float, *, deemph_us: float, agc_enabled: bool):
         self.decoder = create_decoder(mode, deemph_us=deemph_us, agc_enabled=agc_enabled)
         self.decoder.setup(fs_channel)
-        from .decoders.nfm import NarrowbandFMDecoder
-        from .decoders.ssb import SSBDecoder
-
-        d = self.decoder
-        alpha = d._deemph.alpha if isinstance(d, NarrowbandFMDecoder) else 0.0
-        is_ssb = isinstance(d, SSBDecoder)
-        self.params = N.DemodParams(
-            mode=N.DEMOD_MODE[mode.lower()], agc_enabled=int(bool(agc_enabled)), deemph_alpha=alpha,
-            dc_radius=0.995 if isinstance(d, NarrowbandFMDecoder) else d._dc_blocker.radius,
-            agc_target=d._agc_level if is_ssb else 0.0, agc_decay=d._agc_decay if is_ssb else 0.0)
-        self._needs_scratch = is_ssb and bool(agc_enabled)
+        self.params = self.decoder.fused_params()
+        self._needs_scratch = self.params.mode in (N.DEMOD_MODE["usb"], N.DEMOD_MODE["lsb"]) and bool(self.params.agc_enabled)
         self.chunk_sumsq: list = []  # (device float64[n_chunks*8], counts)
         self._blk = None  # one device block: [state 32 B | peak 4 B (+pad to 64) | sumsq n_chunks*8 f64]
         self._starts_key = None

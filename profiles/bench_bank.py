@@ -58,4 +58,6 @@ for mode in modes:
     print(f"{which} {mode}: {ms:.3f} ms per capture of {n_total/1e6:.0f} M frames ({len(targets)} channels, D={d}) = {n_total/ms/1e6:.1f} GS/s of capture; "
           f"algorithmic {algo/1e9:.2f} GB -> {algo/ms/1e6:.0f} GB/s = {algo/ms/1e6/8000:.3f} of 8 TB/s; launch info {info}", flush=True)
 if len(keep) == 2:
-    print("bank == single, bit for bit:", all(torch.equal(a, b) for a, b in zip(keep["bank"], keep["single"])))
+    e = 1024  # (the first and last outputs come from each channel's float32 kernel; a bank's common interior is a little shorter)
+    print("bank == single inside the common matrix-core interior, bit for bit:",
+          all(torch.equal(a[e:-e], b[e:-e]) for a, b in zip(keep["bank"], keep["single"])))

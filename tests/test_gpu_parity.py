@@ -160,9 +160,9 @@ def test_dc_blocker_and_agc(A, golden):
     ssb.setup(96000.0)
     import iq_to_audio_amd._dev as D
 
-    agc = ssb._apply_agc(D.to_device(xr[:2000] * np.float32(0.01), "float32")).cpu().numpy()
+    agc = ssb.agc(D.to_device(xr[:2000] * np.float32(0.01), "float32")).cpu().numpy()
     np.testing.assert_allclose(agc, g["agc"], rtol=2e-5, atol=1e-6)
-    tiny = ssb._apply_agc(D.to_device(g["agc_tiny_in"], "float32")).cpu().numpy()
+    tiny = ssb.agc(D.to_device(g["agc_tiny_in"], "float32")).cpu().numpy()
     np.testing.assert_allclose(tiny, g["agc_tiny"], rtol=2e-5, atol=1e-9)
     with pytest.raises(ValueError):
         DCBlocker(1.5)

@@ -458,3 +458,33 @@ def test_run_benchmark_places_the_tone_like_the_reference(monkeypatch):
     assert seen["offset"] == 25e3 and seen["config"].center_freq == 1.0e8 - 25e3
     B.run_benchmark(center_freq=None, target_freq=None, **kw)
     assert seen["offset"] == 25e3 and (seen["config"].center_freq, seen["config"].target_freq) == (4.0e8, 4.0e8 + 25e3)
+
+
+def test_ring_slot_layout_is_complete_and_conflict_free():
+    """The contiguous ring slots (csrc/channelize_ring.hip, RingGeo / ring_src_off) restated: a tile's 32 rows of D/4
+    16-byte units are fetched by 2*KS + 1 DMA instructions of 64 lanes whose LDS destinations are fixed (instruction base +
+    16 * lane) and whose sources are chosen so that row r sits at an ODD pitch of units.  For every decimation the
+    layout serves (D % 4 == 0, KS <= 13): every unit of every row lands where the fragment reads look for it, the
+    K-padded read of the last row stays inside the slot, and the 16 lanes of every ds_read_b128 lane group
+    (MI355X: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32) touch 16 different bank quads."""
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+
+    def src_unit(idx, lane, ru, pu):  # ring_src_off / 16
+        q = 64 * idx + lane
+        r, u = divmod(q, pu)
+        if r > 31:
+            r, u = 31, ru - 1
+        return r * ru + min(u, ru - 1)
+
+    for d in range(4, 209, 4):
+        ru, ks = d // 4, -(-2 * d // 32)
+        pu, ni = ru | 1, 2 * ks + 1
+        slot = {64 * idx + lane: src_unit(idx, lane, ru, pu) for idx in range(ni) for lane in range(64)}
+        assert all(0 <= v < 32 * ru for v in slot.values())  # nothing outside the tile's own bytes is fetched
+        assert all(slot[r * pu + u] == r * ru + u for r in range(32) for u in range(ru)), d
+        assert 31 * pu + 4 * ks <= 64 * ni  # row 31, last k step (+ K padding) inside the slot
+        for k in range(ks):
+            for first in (0, 1, 2, 3):  # h = 0/1 (2 units apart), two reads per k step
+                for g in groups:
+                    quads = [(col * pu + first + 4 * k) % 16 for col in g]
+                    assert len(set(quads)) == 16, (d, k, first)
