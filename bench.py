@@ -16,15 +16,26 @@ kernels of the next.
 The capture is resident in HBM before the timed region (the first 5 s are the reference's
 seed-42 generator, tiled to 60 s in HBM -- SURVEY.md section 8(d)).
 
+The one JSON line also carries (rank 0, N = 1; all bounded so the default run stays within minutes):
+  value_host_resident -- the same step with the 2.4 GB capture starting in PINNED HOST memory every time (H2D inside
+                         the timed region, double-buffered): the PCIe-inclusive rate.  Never `value`.
+  configs             -- BASELINE config 1 (the reference's own --benchmark capture, 5 s @ 2.5 MS/s) and config 3
+                         (60 s @ 20 MS/s, five simultaneous targets nfm/am/usb/lsb/nfm, AGC on; ONE pass of the
+                         channelizer for all targets) with ms_per_step, roofline fraction and parity per target.
+  roofline.traffic    -- HBM bytes per launch from separate rocprofv3 --pmc passes of this command (profiles/), tagged
+                         with its source; null when no matching profile is committed.  It is NOT measured in this run.
+
 N > 1 (launched by torch.distributed.run): every rank processes its own independent capture
 (BASELINE config 4 pattern, seeds 42+rank), no data-path collective, only the finished 48 kHz
-PCM16 audio is gathered to rank 0 over RCCL (asynchronously, overlapping the next step).  scaling = "weak".
+PCM16 audio is gathered to rank 0 over RCCL (iq_to_audio_amd.dist.AudioGather: asynchronously, overlapping
+the next step).  scaling = "weak".
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -37,6 +48,14 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+C3_TARGETS = [  # offsets, generator / demodulator modes, bandwidths of BASELINE config 3
+    dict(freq_offset=25e3, demod_mode="nfm", bandwidth=12_500.0),
+    dict(freq_offset=-150e3, demod_mode="am", bandwidth=10_000.0),
+    dict(freq_offset=400e3, demod_mode="usb", bandwidth=2_800.0),
+    dict(freq_offset=-1.1e6, demod_mode="lsb", bandwidth=2_800.0),
+    dict(freq_offset=2.3e6, demod_mode="nfm", bandwidth=12_500.0),
+]
 
 
 def parse_args():
@@ -55,7 +74,162 @@ def parse_args():
     ap.add_argument("--unique-seconds", type=float, default=5.0, help="seed-42 prefix generated on the host, then tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_resident and the configs array")
     return ap.parse_args()
+
+
+def rms_err(a, b) -> float:
+    return float(np.sqrt(np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2)))
+
+
+def padded_resident(host_i16: np.ndarray, n_total: int, slack: int):
+    """The capture tiled to ``n_total`` frames inside a slightly larger device buffer (readable slack behind it)."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+
+    tile = torch.from_numpy(host_i16).to(D.device())
+    buf = torch.zeros(2 * (n_total + slack), dtype=torch.int16, device=D.device())
+    buf[: 2 * n_total] = tile.repeat(-(-2 * n_total // tile.numel()))[: 2 * n_total]
+    del tile
+    return buf
+
+
+def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
+    """BASELINE config 1: the reference's --benchmark capture (5 s @ 2.5 MS/s, NFM, +25 kHz) through the same runner."""
+    import torch
+
+    import iq_to_audio_amd as A
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
+    from oracle import cpu_ref as O
+
+    fs, secs, f_off = 2.5e6, 5.0, 25e3
+    n = int(round(fs * secs))
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    host = O.synth_capture_s16(fs, secs, f_off).reshape(-1)
+    _, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    buf = padded_resident(host, n, slack)
+    raw = buf[: 2 * n]
+    torch.cuda.synchronize()
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch,
+                                   chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    ts = [runner.submit(raw, enclosing=buf, lead_frames=0, resident=True) for _ in range(warm)]
+    for t in ts:
+        runner.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = [runner.submit(raw, events=ev[i], enclosing=buf, lead_frames=0, resident=True) for i in range(steps)]
+    res = [runner.collect(t) for t in ts][-1]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    want = O.run_chain(host, sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+    audio = res["audio"].cpu().numpy()
+    algo = (4.0 + 4.0 * 48_000.0 / fs) * n
+    return {
+        "workload": "BASELINE config 1 (the reference's --benchmark capture): 5 s @ 2.5 MS/s int16 I/Q, 1 NFM channel, +25 kHz, "
+                    f"bw 12.5 kHz, D={d}, {len(taps)} taps",
+        "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
+        "roofline": {"kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
+                     "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+        "parity": {"rms_err_vs_oracle_fs_channel": rms_err(audio, want.audio), "samples_compared": int(want.audio.size),
+                   "sample_count_exact": bool(audio.size == want.audio.size), "bar": 1e-4},
+    }
+
+
+def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 0.55) -> dict:
+    """BASELINE config 3: 60 s @ 20 MS/s, five simultaneous targets (nfm/am/usb/lsb/nfm, bw 12.5k/10k/2.8k/2.8k/12.5k),
+    AGC on -- one pass of the channelizer over the capture for all targets (ResidentBankRunner)."""
+    import torch
+
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentBankRunner, ResidentCaptureRunner
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+    from oracle import cpu_ref as O
+
+    fs, secs, uniq = 20e6, 60.0, 2.0
+    n = int(round(fs * secs))
+    d, _ = P.choose_decimation(fs, 96_000.0)
+    carriers = [(t["freq_offset"], 0.14, t["demod_mode"]) for t in C3_TARGETS]
+    host = synthetic_multi_iq_s16(fs, uniq, carriers).reshape(-1)
+    slack = max(ResidentCaptureRunner.padded_capture_frames(d, 32_769)[1], 8192)
+    buf = padded_resident(host, n, slack)
+    raw = buf[: 2 * n]
+    torch.cuda.synchronize()
+    runner = ResidentBankRunner(C3_TARGETS, sample_rate=fs, n_frames=n)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for t in [runner.submit(raw, enclosing=buf, lead_frames=0) for _ in range(warm)]:
+        runner.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = [runner.submit(raw, events=ev[i], enclosing=buf, lead_frames=0) for i in range(steps)]
+    res = [runner.collect(t) for t in ts][-1]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    chan_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    launch = ts[-1]["launch"]
+    # parity per target on the un-tiled prefix (whole reference chunks are not needed: the oracle sees the same frames)
+    n_cpu = int(round(cpu_seconds_of_signal * fs))
+    parity = []
+    for spec, r in zip(C3_TARGETS, res):
+        want = O.run_chain(host[: 2 * n_cpu], sample_rate=fs, freq_offset=spec["freq_offset"], bandwidth=spec["bandwidth"],
+                           demod_mode=spec["demod_mode"], agc_enabled=True)
+        k = want.audio.size - 64  # (the capture continues behind the oracle's sample: its last outputs see other frames)
+        z_err = rms_err(np.abs(r["z"][:k].cpu().numpy() - want.decimated[:k]), 0.0)
+        entry = {"target": f'{spec["demod_mode"]} {spec["freq_offset"]:+.0f} Hz bw {spec["bandwidth"]:.0f}', "sign": r["sign"],
+                 "z_rms_err": z_err, "samples_compared": int(k)}
+        if spec["demod_mode"] in ("usb", "lsb"):
+            entry["note"] = ("SSB + AGC is ill-conditioned in the reference (DESIGN.md section 5): the audio is held link by "
+                             "link in tests/test_gpu_configs.py; z is the parity figure here")
+        else:
+            entry["audio_rms_err"] = rms_err(r["audio"][:k].cpu().numpy(), want.audio[:k])
+        parity.append(entry)
+    algo = 4.0 * n + len(C3_TARGETS) * 4.0 * 48_000.0 / fs * n
+    return {
+        "workload": "BASELINE config 3: 60 s @ 20 MS/s int16 I/Q, 5 simultaneous targets nfm/am/usb/lsb/nfm "
+                    f"(12801/16001/32769/32769/12801 taps = {launch['lanes'] if launch else '?'} tap-row-group lanes), AGC on, D={d}",
+        "value": round(n / dt / 1e6, 1), "unit": "MS/s of capture", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        "channel_samples_per_s": round(len(C3_TARGETS) * n / dt / 1e9, 2),
+        "roofline": {"kernel": res and ts[-1]["kernel"] + "_multi", "launch": launch, "kernel_ms": round(chan_ms, 4),
+                     "note": "kernel_ms = the one multi-lane channelizer pass (+ its combine launches) per capture, by events",
+                     "algorithmic_bytes_per_launch": algo, "achieved": round(algo / (chan_ms * 1e-3) / 1e9, 2),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(algo / (chan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+        "parity": {"bar": 1e-4, "per_target": parity},
+    }
+
+
+def host_resident_leg(runner, host_pinned, bufs, n_total: int, captures: int = 8) -> dict:
+    """The step with the capture starting in pinned host memory: its upload (2.4 GB over PCIe) is inside the timed
+    region, double-buffered against the previous capture's kernels."""
+    import torch
+
+    up = torch.cuda.Stream()
+
+    def step(i):
+        buf = bufs[i % 2]
+        with torch.cuda.stream(up):  # upload of capture i beside the kernels of capture i-1
+            buf[: 2 * n_total].copy_(host_pinned, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        torch.cuda.current_stream().wait_event(ev)
+        return runner.submit(buf[: 2 * n_total], enclosing=buf, lead_frames=0)
+
+    for t in [step(i) for i in range(2)]:
+        runner.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in [step(i) for i in range(captures)]:
+        runner.collect(t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / captures
+    return {"value": round(n_total / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 2), "steps": captures,
+            "pcie_gb_per_s": round(4.0 * n_total / dt / 1e9, 1),
+            "note": "capture in pinned host memory at the start of every step (H2D inside the timed region, double-buffered); "
+                    "bounded by the PCIe link, not the GPU"}
 
 
 def main() -> None:
@@ -67,29 +241,22 @@ def main() -> None:
     os.dup2(2, 1)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (see iq_to_audio_amd/__init__.py; before the runtime initialises)
     import torch
-    import torch.distributed as dist
 
     import iq_to_audio_amd as A
     from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dist as DS
     from iq_to_audio_amd import dsp_plan as P
-    from iq_to_audio_amd.benchmark import synthetic_iq_s16
     from iq_to_audio_amd.batch import ResidentCaptureRunner
+    from iq_to_audio_amd.benchmark import synthetic_iq_s16
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # the launch is validated before anything touches a GPU (device_count() does not initialise one on this image)
+    rank, world, local_rank = DS.check_launch_env(args.gpus, torch.cuda.device_count())
     A.native.lib()
-    A.native.require_gpu()
-    torch.cuda.set_device(local_rank)
-    # IQA_BENCH_FORCE_DIST=1: rehearse the N > 1 code path (process group, per-capture gather, barrier, max over ranks)
+    # IQA_FORCE_DIST=1: rehearse the N > 1 code path (process group, per-capture gather, barrier, max over ranks)
     # with a single rank on a one-GPU box
-    distributed = world > 1 or bool(os.environ.get("IQA_BENCH_FORCE_DIST"))
+    distributed = world > 1 or bool(os.environ.get("IQA_FORCE_DIST") or os.environ.get("IQA_BENCH_FORCE_DIST"))
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("IQA_FORCE_DIST", "1")
         # RCCL's send/recv kernel needs 19.7 KB of LDS and ~280 VGPRs per workgroup (librccl's gfx950 code object): it
         # cannot share a CU with a channelizer workgroup (149 KB of LDS at D = 104), and a channelizer launch that wants
         # all 256 CUs waits for every CU a gather still sits on.  So with a gather in the job the capture-long launches
@@ -99,16 +266,10 @@ def main() -> None:
         from iq_to_audio_amd import processing as _PR
 
         _PR._ChannelKernel.launch_blocks = int(os.environ.get("IQA_BENCH_RING_BLOCKS", "240"))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # RCCL's kernels on a high-priority stream: the audio gather shares the GPU with a channelizer that holds
-        # every CU for half a millisecond at a time
-        opts = None
-        try:
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        except Exception:  # pragma: no cover - older builds
-            opts = None
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+    torch.cuda.set_device(local_rank)
+    A.native.require_gpu()
+    if distributed:
+        DS.init_from_env("nccl", high_priority=True)
 
     fs, f_off, bw = float(args.sample_rate), 25e3, 12_500.0
     n_total = int(round(fs * args.seconds))
@@ -119,15 +280,11 @@ def main() -> None:
 
     # ---- synthetic capture, resident in HBM ---------------------------------------------------
     host = synthetic_iq_s16(fs, n_unique / fs, f_off, seed=42 + rank).reshape(-1)
-    tile = torch.from_numpy(host).to(D.device())
-    reps = -(-n_total // n_unique)
     # the capture sits inside a slightly larger buffer: a few KB of readable slack behind it make the last outputs
     # interior outputs of the matrix-core kernel too (no VALU tail launch)
     lead, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
-    buf = torch.zeros(2 * (lead + n_total + slack), dtype=torch.int16, device=D.device())
-    buf[2 * lead : 2 * (lead + n_total)] = tile.repeat(reps)[: 2 * n_total]
-    raw = buf[2 * lead : 2 * (lead + n_total)]
-    del tile
+    buf = padded_resident(host, n_total, slack)
+    raw = buf[: 2 * n_total]
     torch.cuda.synchronize()
 
     # one runner per configuration: plans are made once, every step queues probes + channelizer + demod/resample/PCM16
@@ -135,51 +292,36 @@ def main() -> None:
     runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
                                    n_frames=n_total, demod_mode="nfm", deemph_us=300.0, agc_enabled=True, fmt="s16")
     n48 = runner.n48
-    # finished 48 kHz PCM16 audio of every capture is gathered on rank 0 (as bytes: RCCL has no int16 type)
-    gathered = [torch.empty(2 * n48, dtype=torch.uint8, device=D.device()) for _ in range(world)] if (distributed and rank == 0) else None
-    pending = []
+    # finished 48 kHz PCM16 audio of every capture is gathered on rank 0 (as bytes: RCCL has no int16 type), on the
+    # runner's egress stream, at most one gather in flight
+    gather = DS.AudioGather(2 * n48, dst=0, stream=runner.egress, device=D.device()) if distributed else None
     settle = max(0, args.settle - args.warmup)
     n_untimed = settle + args.warmup
     ev_k0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + n_untimed)]
     ev_k1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + n_untimed)]
     tickets = []
-
     lag = []  # the capture whose audio has not been handed to the gather yet
-
-    def queue_gather(t, after):
-        runner.egress.wait_event(after)  # t's PCM16 is complete
-        with torch.cuda.stream(runner.egress):  # the gather overlaps the next captures' kernels
-            while pending:
-                pending.pop().wait()  # at most one gather in flight: the receive buffers are reused
-            t["pcm"].record_stream(runner.egress)
-            pending.append(dist.gather(t["pcm"].view(torch.uint8), gathered, dst=0, async_op=True))
 
     def step(i: int):
         # resident: the capture was complete in HBM before the timed region (the metric's premise)
         t = runner.submit(raw, events=(ev_k0[i], ev_k1[i]), enclosing=buf, lead_frames=lead, resident=True)
         tickets.append(t)
-        if distributed:
+        if gather is not None:
             # the PREVIOUS capture's audio goes to the gather now: this capture's first timing event lies behind its
             # last kernel, so no event of its own is needed (an event record costs the compute stream ~7 us)
             if lag:
-                queue_gather(lag.pop(), ev_k0[i])
+                gather.queue(lag.pop()["pcm"], after=ev_k0[i])
             lag.append(t)
         return t
 
     def fence():
         if lag:  # the last capture's audio
             t = lag.pop()
-            queue_gather(t, runner.tail_event(t))
+            gather.queue(t["pcm"], after=runner.tail_event(t))
         for t in tickets:
             runner.collect(t)
         del tickets[:]
-        while pending:
-            pending.pop().wait()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    import gc
+        DS.fence(gather, sync=torch.cuda.synchronize)
 
     # Everything slow on the host happens BEFORE the first capture: a generation-2 collection in the middle of a 0.7 ms
     # step is a 10-70 ms stall, and that much idle GPU starts the power-management transient all over again.
@@ -206,11 +348,8 @@ def main() -> None:
         print("host-side step completion times (ms):", [round(m * 1e3, 2) for m in marks[:80]],
               "after fence:", round((time.perf_counter() - t0) * 1e3, 2),
               "allocator deltas:", {k: stats1.get(k, 0) - stats0.get(k, 0) for k in keys}, file=sys.stderr)
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=D.device())
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = DS.max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
 
     kern_ms = [ev_k0[n_untimed + i].elapsed_time(ev_k1[n_untimed + i]) for i in range(args.steps)]
     if os.environ.get("IQA_BENCH_DEBUG"):
@@ -228,13 +367,15 @@ def main() -> None:
     bytes_per_sample = 4.0 + 1 * 4.0 * 48_000.0 / fs
     algo_bytes = bytes_per_sample * n_total
     achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_source = None
     pmc = ROOT / "profiles" / "pmc_summary.json"
     if pmc.exists():
         with pmc.open() as fh:
             rec = json.load(fh)
         if rec.get("workload_frames") == n_total and kernel_name[0] in (rec.get("kernel") or ""):
             traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              f"command ({rec.get('tag', 'untagged')}), (2 x FETCH_SIZE + WRITE_SIZE) x 1024; NOT measured in this run")
 
     label = ("BASELINE config 1 (the reference's --benchmark capture)" if (fs, args.seconds) == (2.5e6, 5.0) else
              "BASELINE config 2" if (fs, args.seconds) == (10e6, 60.0) else
@@ -260,6 +401,7 @@ def main() -> None:
             "audio_samples_48k": int(n48),
             "mix_sign": int(sign),
             "settle_steps": settle,
+            "residency": "capture resident in HBM before the timed region (value); see value_host_resident for the PCIe-inclusive rate",
         },
         "roofline": {
             "bound": "hbm",
@@ -269,11 +411,14 @@ def main() -> None:
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel_ms": round(kern_avg_ms, 4),
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_gsps": round(n_total / (kern_avg_ms * 1e-3) / 1e9, 2),
         },
     }
+    if gather is not None:
+        out["config"]["gathers"] = gather.count
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cpu_ref as O
@@ -287,7 +432,6 @@ def main() -> None:
         cpu_s = time.perf_counter() - t1
         # parity of the benchmarked GPU output against the oracle on the same sample
         got = audio[: ref.audio.size].cpu().numpy()
-        err = float(np.sqrt(np.mean((got.astype(np.float64) - ref.audio) ** 2)))
         out["cpu_baseline"] = {
             "value": round(n_cpu / cpu_s / 1e6, 2),
             "unit": "MS/s",
@@ -297,9 +441,32 @@ def main() -> None:
                       f"(fp64 NCO + complex128 131072-pt scipy.fft overlap-save + slice decimate + NFM), "
                       f"{cpu_s:.1f} s on 1 of {os.cpu_count()} host cpus (1-D FFTs are single-threaded)",
         }
-        out["parity"] = {"rms_err_vs_oracle_fs_channel": err, "samples_compared": int(ref.audio.size), "bar": 1e-4}
+        out["parity"] = {"rms_err_vs_oracle_fs_channel": rms_err(got, ref.audio), "samples_compared": int(ref.audio.size), "bar": 1e-4}
+
+    if rank == 0 and world == 1 and not args.no_extras and not distributed:
+        # -- the same step from pinned host memory (PCIe-inclusive; never `value`) --------------------------------
+        try:
+            host_pinned = torch.from_numpy(np.tile(host, -(-2 * n_total // host.size))[: 2 * n_total]).pin_memory()
+            second = torch.zeros_like(buf)
+            out["value_host_resident"] = host_resident_leg(runner, host_pinned, [buf, second], n_total)
+            del host_pinned, second
+        except Exception as exc:  # noqa: BLE001 - an extra must never take the headline down
+            out["value_host_resident"] = {"error": repr(exc)}
+        del runner, raw, buf
+        torch.cuda.empty_cache()
+        # -- the other single-GPU BASELINE configurations ------------------------------------------------------
+        out["configs"] = []
+        for fn in (sub_bench_c1, sub_bench_c3):
+            try:
+                out["configs"].append(fn())
+            except Exception as exc:  # noqa: BLE001
+                out["configs"].append({"workload": fn.__name__, "error": repr(exc)})
+            gc.collect()
+            torch.cuda.empty_cache()
 
     if distributed:
+        import torch.distributed as dist
+
         dist.destroy_process_group()
     sys.stdout.flush()
     os.dup2(json_fd, 1)

@@ -14,7 +14,7 @@ import numpy as np
 from . import _dev as D
 from . import _native as N
 from . import dsp_plan as P
-from .processing import ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps
+from .processing import ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps
 
 
 class ResidentCaptureRunner:
@@ -218,3 +218,161 @@ class ResidentCaptureRunner:
         ticket["result"] = dict(pcm_host=slot["pcm_host"], sign=int(sign), audio=slot["audio"], z=slot["z"],
                                 kernel=ticket["kernel"], demod=ticket["dem"], done=ticket["done"])
         return ticket["result"]
+
+
+class ResidentBankRunner:
+    """Several ``--ft`` targets of whole captures that already sit in HBM (BASELINE config 3; config 5's per-GPU unit).
+
+    The reference runs one pipeline per target over the same file (cli.py:683-710).  Here one ``submit`` queues, for one
+    resident capture: every target's two mixer-sign probes (``choose_mix_sign``, processing.py:623-663), ONE pass of the
+    channelizer over the capture for all targets (:class:`processing.ChannelBank`, run speculatively for sign +1 like
+    :class:`ResidentCaptureRunner`), then per target the fused demodulator + writer clip, the 48 kHz resampler with PCM16
+    output and the copy of that PCM16 into pinned host memory -- all on the caller's stream, no host<->device
+    synchronisation.  ``collect`` waits, reads the probes back and re-runs the targets whose probe chose -1.
+    """
+
+    SLOTS = 2
+
+    def __init__(self, targets: list, *, sample_rate: float, n_frames: int, chunk_size: int = 1_048_576,
+                 fs_ch_target: float = 96_000.0, fmt: str = "s16", iq_order: str = "iq"):
+        """``targets``: dicts with ``freq_offset``, and optionally ``bandwidth`` (12 500), ``demod_mode`` ("nfm"),
+        ``deemph_us`` (300), ``agc_enabled`` (True), ``mix_sign`` (None = probe)."""
+        torch = D.torch_mod()
+        if not targets:
+            raise ValueError("at least one target is required")
+        self.fs, self.n_frames, self.fmt, self.iq_order = float(sample_rate), int(n_frames), fmt, iq_order
+        self.d, self.fs_ch = P.choose_decimation(self.fs, fs_ch_target)
+        self.chunk = P.tune_chunk_size(self.fs, chunk_size)
+        self.n_dec = -(-self.n_frames // self.d)
+        self.starts = P.chunk_output_starts(self.chunk, self.d, 0, self.n_frames)
+        self.rs = Resampler48k(self.fs_ch)
+        self.n48 = self.rs.plan.n_out(self.n_dec)
+        self.targets = []
+        for t in targets:
+            spec = dict(bandwidth=12_500.0, demod_mode="nfm", deemph_us=300.0, agc_enabled=True, mix_sign=None)
+            spec.update(t)
+            spec["taps"] = immutable_taps(P.design_channel_filter(self.fs, spec["bandwidth"], self.d))
+            self.targets.append(spec)
+        self.slots = []
+        for _ in range(self.SLOTS):
+            per = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
+                        pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(),
+                        dem=ChannelDemod(s["demod_mode"], self.fs_ch, deemph_us=s["deemph_us"], agc_enabled=s["agc_enabled"]))
+                   for s in self.targets]
+            self.slots.append(dict(per=per, busy=None))
+        self._next = 0
+
+    def _channelizer(self, spec, sign: int) -> Channelizer:
+        return Channelizer(spec["taps"], sample_rate=self.fs, freq_offset=spec["freq_offset"], mix_sign=sign, decimation=self.d,
+                           fmt=self.fmt, iq_order=self.iq_order)
+
+    def _finish_target(self, per, raw_unused=None) -> None:
+        """Demodulator + writer clip, 48 kHz PCM16, copy to the host: for one target's z."""
+        dem = per["dem"]
+        dem.reset()
+        dem.process(per["z"], self.starts, per["audio"])
+        pcm = self.rs.process(per["audio"], want="pcm16")
+        per["pcm_host"].copy_(pcm, non_blocking=True)
+
+    def submit(self, raw_dev, enclosing=None, lead_frames: int = 0, events=None) -> dict:
+        """Queue one capture; ``events``: optional pair of torch events recorded around the channelizer's pass."""
+        torch = D.torch_mod()
+        slot = self.slots[self._next % self.SLOTS]
+        self._next += 1
+        if slot["busy"] is not None:
+            self.collect(slot["busy"])
+        warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
+        probes = [None if s["mix_sign"] in (1, -1) else
+                  MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order)
+                  for s in self.targets]
+        signs = [s["mix_sign"] if s["mix_sign"] in (1, -1) else 1 for s in self.targets]
+        chans = [self._channelizer(s, sg) for s, sg in zip(self.targets, signs)]
+        for c in chans:
+            c.plan_ahead()
+        halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        if events:
+            events[0].record()
+        bank = ChannelBank(chans)
+        bank.process(raw_dev, outs=[p["z"] for p in slot["per"]], last_block=True, halo=halo)
+        if events:
+            events[1].record()
+        for per in slot["per"]:
+            self._finish_target(per)
+        done = torch.cuda.Event()
+        done.record()
+        ticket = dict(slot=slot, probes=probes, signs=signs, raw=raw_dev, halo=halo, done=done, launch=bank.last_launch,
+                      kernel=chans[0]._kernel.last_kernel, collected=False)
+        slot["busy"] = ticket
+        return ticket
+
+    def collect(self, ticket: dict) -> list:
+        """Wait for a capture.  Returns one dict per target: {"pcm_host", "audio", "z", "sign", "demod"}; the buffers
+        belong to the runner and are reused ``SLOTS`` submits later."""
+        if ticket["collected"]:
+            return ticket["result"]
+        slot = ticket["slot"]
+        ticket["done"].synchronize()
+        redo = False
+        for i, (probe, per, spec) in enumerate(zip(ticket["probes"], slot["per"], self.targets)):
+            if probe is None:
+                continue
+            sign = probe.result()
+            if sign != ticket["signs"][i]:  # the speculation was wrong for this target: its channel again, alone
+                ticket["signs"][i] = sign
+                self._channelizer(spec, sign).process(ticket["raw"], out_dev=per["z"], last_block=True, halo=ticket["halo"])
+                self._finish_target(per)
+                redo = True
+        if redo:
+            D.torch_mod().cuda.current_stream().synchronize()
+        ticket["collected"] = True
+        ticket["raw"] = None
+        if slot["busy"] is ticket:
+            slot["busy"] = None
+        ticket["result"] = [dict(pcm_host=per["pcm_host"], audio=per["audio"], z=per["z"], sign=int(sg), demod=per["dem"])
+                            for per, sg in zip(slot["per"], ticket["signs"])]
+        return ticket["result"]
+
+
+def demodulate_sharded(targets: list, *, sample_rate: float, n_frames: int, axis: str, capture=None, captures=None,
+                       chunk_size: int = 1_048_576, fmt: str = "s16", iq_order: str = "iq"):
+    """The N-GPU form of :class:`ResidentBankRunner` (one process per GPU under ``torch.distributed.run``; SURVEY.md
+    section 8(e)), on either axis:
+
+    * ``axis="channels"`` -- **channels of one capture** (BASELINE config 5): ``capture`` is the 1-D tensor of interleaved
+      values on rank 0 (``None`` on the other ranks); it is replicated with ONE RCCL broadcast, every rank extracts its
+      contiguous share of ``targets`` in one pass over it (a bank), rank 0 receives every target's 48 kHz PCM16.
+      Returns ``({target index: int16 ndarray}, peak)`` on rank 0.
+    * ``axis="captures"`` -- **independent captures** (config 4): ``captures`` has one entry per capture, a 1-D tensor or a
+      zero-argument callable that loads one (only the owning rank calls it); every rank runs all ``targets`` on its share.
+      Returns ``({capture index: int16 ndarray of shape (len(targets), n48)}, peak)`` on rank 0.
+
+    ``(None, peak)`` on the other ranks; without a process group it is the single-GPU path.  The only collectives are
+    the broadcast (channel axis) and the final gather of the audio."""
+    from . import dist as DS
+
+    torch = D.torch_mod()
+    if axis not in ("channels", "captures"):
+        raise ValueError("axis must be 'channels' or 'captures'")
+
+    def run_bank(specs, raw_dev):
+        runner = ResidentBankRunner(specs, sample_rate=sample_rate, n_frames=n_frames, chunk_size=chunk_size, fmt=fmt, iq_order=iq_order)
+        res = runner.collect(runner.submit(raw_dev))
+        return [(torch.from_numpy(r["pcm_host"].numpy().copy()).to(raw_dev.device), r["demod"].peak) for r in res]
+
+    if axis == "channels":
+        dtype = {"s16": torch.int16, "u8": torch.uint8, "f32": torch.float32}[fmt]
+        shared = dict(tensor=capture, numel=2 * n_frames, dtype=dtype, device=D.device())
+        return DS.run_sharded(list(targets), run_bank, shared=shared)
+
+    def every_target_of(mine, _):
+        out = []
+        for unit in mine:
+            raw = (unit() if callable(unit) else unit).to(D.device())
+            res = run_bank(list(targets), raw)
+            out.append((torch.cat([a for a, _ in res]), max(p for _, p in res)))
+        return out
+
+    got, peak = DS.run_sharded(list(captures), every_target_of)
+    if got is not None:
+        got = {k: v.reshape(len(targets), -1) for k, v in got.items()}
+    return got, peak

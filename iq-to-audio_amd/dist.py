@@ -164,7 +164,7 @@ def broadcast_capture(capture, numel: int, dtype, *, src: int = 0, device=None):
         buf = capture.to(dev)
     else:
         buf = torch.empty(numel, dtype=dtype, device=dev)
-    dist.broadcast(buf, src=src)
+    dist.broadcast(buf.view(torch.uint8), src=src)  # as bytes: neither RCCL nor gloo has an int16 type
     return buf
 
 
@@ -173,7 +173,8 @@ def run_sharded(units: list, stage, *, shared=None, dst: int = 0):
 
     ``units``: descriptors of the independent pieces of work -- whole captures (BASELINE config 4) or channels of one
     capture (config 5); every rank takes a contiguous share (:func:`shard_units`).
-    ``stage(unit, shared) -> (audio 1-D tensor, peak float)``: the single-GPU hot path for one unit.
+    ``stage(my_units, shared) -> [(audio 1-D tensor, peak float), ...]``: the single-GPU hot path for ALL of a rank's
+    units at once (so that the channels of a capture can share one pass over it), one result per unit, in order.
     ``shared``: ``None`` (capture axis: a unit brings its own capture) or ``dict(tensor=..., numel=..., dtype=...)`` --
     the capture all units read, present on ``dst`` and replicated to every rank with one broadcast before any unit runs.
     Returns ``({unit index: np.ndarray}, peak)`` on ``dst`` and ``(None, peak)`` elsewhere; ``peak`` is the max over all
@@ -186,11 +187,11 @@ def run_sharded(units: list, stage, *, shared=None, dst: int = 0):
         common = broadcast_capture(shared.get("tensor"), int(shared["numel"]), shared["dtype"], src=dst,
                                    device=shared.get("device"))
     mine = shard_units(len(units), rank, world)
-    audio, peak = [], 0.0
-    for u in mine:
-        a, p = stage(units[u], common)
-        audio.append(a)
-        peak = max(peak, float(p))
+    results = list(stage([units[u] for u in mine], common)) if mine else []
+    if len(results) != len(mine):
+        raise RuntimeError(f"stage returned {len(results)} results for {len(mine)} units")
+    audio = [a for a, _ in results]
+    peak = max([float(p) for _, p in results], default=0.0)
     gathered = gather_audio(audio, mine, len(units), dst=dst)
     return gathered, max_over_ranks(peak)
 

@@ -59,5 +59,6 @@ for mode in modes:
           f"algorithmic {algo/1e9:.2f} GB -> {algo/ms/1e6:.0f} GB/s = {algo/ms/1e6/8000:.3f} of 8 TB/s; launch info {info}", flush=True)
 if len(keep) == 2:
     e = 1024  # (the first and last outputs come from each channel's float32 kernel; a bank's common interior is a little shorter)
-    print("bank == single inside the common matrix-core interior, bit for bit:",
-          all(torch.equal(a[e:-e], b[e:-e]) for a, b in zip(keep["bank"], keep["single"])))
+    print("bank vs single inside the common matrix-core interior: max |diff| =",
+          max(float((a[e:-e] - b[e:-e]).abs().max()) for a, b in zip(keep["bank"], keep["single"])),
+          "(same integer sums; the float rotation recurrence restarts per workgroup range)")

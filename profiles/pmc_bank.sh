@@ -1,0 +1,42 @@
+#!/bin/bash
+# PMC passes for the multi-lane (shared-ingest) channelizer on BASELINE config 3's shape.  Usage: profiles/pmc_bank.sh <tag> [c3|c5]
+# Separate passes, --pmc only (no tracing), as the pool requires.  FETCH_SIZE is doubled in the summary (gfx950: wide
+# coalesced reads are tallied at half their bytes, MI355X_MICROARCH.md HBM section).
+set -u
+TAG=${1:-x}
+WHICH=${2:-c3}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/pmc_bank_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+export K=${K:-6} WARM=${WARM:-2}
+CMD="python3 $R/profiles/bench_bank.py $WHICH bank"
+timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
+timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
+timeout -k 10 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
+timeout -k 10 250 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d "$OUT/p1" -- $CMD > "$OUT/p1.log" 2>&1
+timeout -k 10 250 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d "$OUT/p2" -- $CMD > "$OUT/p2.log" 2>&1
+timeout -k 10 250 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/p3" -- $CMD > "$OUT/p3.log" 2>&1
+python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"
+import csv, glob, sys
+from collections import defaultdict
+out = sys.argv[1]
+fs = glob.glob(f"{out}/stats/**/*kernel_stats.csv", recursive=True)
+if fs:
+    print("kernel stats (rocprofv3 --kernel-trace --stats):")
+    for r in csv.DictReader(open(fs[0])):
+        print("  ", {k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+for p in ("fetch", "write", "p1", "p2", "p3"):
+    fs = glob.glob(f"{out}/{p}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        print(p, "no counters; tail of log:"); print(open(f"{out}/{p}.log").read()[-600:]); continue
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "ring" in r["Kernel_Name"] and "multi" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        med = sorted(v)[len(v) // 2]
+        extra = (f"  KiB -> HBM read bytes = 2 x 1024 x = {2 * med * 1024:.5g}" if k == "FETCH_SIZE" else
+                 f"  KiB -> HBM written bytes = {med * 1024:.5g}" if k == "WRITE_SIZE" else "")
+        print(f"{p} {k:32s} n={len(v)} median={med:.6g}{extra}")
+PY

@@ -348,11 +348,11 @@ def test_config5_unit_five_nfm_channels(A, tmp_path):
     # uint8 capture, odd decimation (RTL-SDR rate)
     (2.4e6, "u8", [(25e3, 12_500.0, 1), (-300e3, 12_500.0, 1)], 5_000_000),
 ])
-def test_channel_bank_is_bit_identical_to_one_channel_at_a_time(A, fs, fmt, specs, n):
+def test_channel_bank_equals_one_channel_at_a_time(A, fs, fmt, specs, n):
     """ChannelBank (one launch of the ring kernel for all channels of a capture, iqa_channelize_mfma_multi +
     iqa_mfma_combine) against the same channelizers run one by one: the same integers are added in the same order, so
-    the decimated streams must be EQUAL bit for bit -- over two ragged blocks (history, decimator phase) and with
-    mixed mixer signs.  One channel is also held against the oracle so that the pair is not jointly wrong."""
+    the decimated streams must agree to the last bit of the float32 rotation -- over two ragged blocks (history,
+    decimator phase) and with mixed mixer signs.  One channel is also held against the oracle so that the pair is not jointly wrong."""
     import torch
 
     from iq_to_audio_amd import _dev as D
@@ -390,7 +390,12 @@ def test_channel_bank_is_bit_identical_to_one_channel_at_a_time(A, fs, fmt, spec
         assert sum(t.numel() for t in one) == sum(t.numel() for t in many) == -(-n // d)
         for blk, (a_, b_) in enumerate(zip(one, many)):
             assert a_.numel() == b_.numel()
-            assert torch.equal(a_[edge:-edge], b_[edge:-edge]), (i, blk, float((a_ - b_)[edge:-edge].abs().max()))
+            # same integer sums; the float64 rotation recurrence starts at each workgroup's first output and a bank cuts
+            # the launch into other ranges than a single channel does: where cos/sin sit on a float32 rounding boundary
+            # the last bit of an output may differ
+            inner = (a_ - b_)[edge:-edge]
+            assert float(inner.abs().max()) <= 1.2e-7 * float(a_.abs().max()), (i, blk, float(inner.abs().max()))
+            assert float((inner != 0).float().mean()) < 1e-3, (i, blk)
             assert float((a_ - b_).abs().max()) < 2e-4  # the edges: float32 kernel vs fixed-point kernel
     banked = [torch.cat(pair) for pair in banked]
     off, bw, sign = specs[0]
@@ -401,3 +406,44 @@ def test_channel_bank_is_bit_identical_to_one_channel_at_a_time(A, fs, fmt, spec
     got = banked[0].cpu().numpy()[: want.size]
     assert rms(got - want) < 1.4e-5 * max(1.0, float(np.sqrt(len(taps) / 6401.0)))
     assert rms(want) > 0.05
+
+
+def test_resident_bank_runner_matches_the_oracle_per_target(A):
+    """batch.ResidentBankRunner (what bench.py's config-3 entry and batch.demodulate_sharded run): four targets of one
+    resident capture at the C2 rate -- two of them multi-group filters, one whose carrier sits on the other side so that
+    its probe overrules the speculative sign +1 -- every target's channel-rate audio and 48 kHz PCM16 against its own
+    oracle chain; two captures back to back through the two buffer slots."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd.batch import ResidentBankRunner
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+
+    fs, secs = 10e6, 0.9
+    targets = [dict(freq_offset=25e3, demod_mode="nfm", bandwidth=12_500.0), dict(freq_offset=-150e3, demod_mode="am", bandwidth=10_000.0),
+               dict(freq_offset=400e3, demod_mode="usb", bandwidth=2_800.0, agc_enabled=False),
+               dict(freq_offset=1.1e6, demod_mode="nfm", bandwidth=12_500.0)]
+    caps = []
+    for seed in (42, 43):
+        carriers = [(25e3, 0.2, "nfm"), (-150e3, 0.2, "am"), (400e3, 0.2, "usb"), (-1.1e6, 0.2, "nfm")]  # last one mirrored
+        caps.append(synthetic_multi_iq_s16(fs, secs, carriers, seed=seed))
+    n = caps[0].shape[0]
+    runner = ResidentBankRunner(targets, sample_rate=fs, n_frames=n)
+    devs = [D.to_device(c.reshape(-1), "int16") for c in caps]
+    torch.cuda.synchronize()
+    tickets = [runner.submit(x) for x in devs]
+    assert tickets[0]["launch"] == dict(lanes=1 + 1 + 2 + 1, launches=1, combines=1)  # 6401 / 8001 / 16385 (2 groups) / 6401 taps
+    for cap, ticket in zip(caps, tickets):
+        res = runner.collect(ticket)
+        for spec, r in zip(targets, res):
+            want = O.run_chain(cap, sample_rate=fs, freq_offset=spec["freq_offset"], bandwidth=spec["bandwidth"],
+                               demod_mode=spec["demod_mode"], agc_enabled=spec.get("agc_enabled", True), keep_decimated=False)
+            assert r["sign"] == want.mix_sign == (-1 if spec["freq_offset"] == 1.1e6 else 1)
+            audio = r["audio"].cpu().numpy()
+            assert audio.size == want.audio.size
+            assert rms(audio - want.audio) < 2e-5, (spec, rms(audio - want.audio))
+            ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+            pcm = r["pcm_host"].numpy()
+            assert pcm.size == ref48.size == runner.n48
+            assert np.max(np.abs(pcm.astype(np.int32) - ref48.astype(np.int32))) <= 2
+            assert abs(r["demod"].peak - want.audio_peak) < 1e-4 * max(1.0, want.audio_peak)
