@@ -410,7 +410,7 @@ def test_channel_bank_equals_one_channel_at_a_time(A, fs, fmt, specs, n):
 
 def test_resident_bank_runner_matches_the_oracle_per_target(A):
     """batch.ResidentBankRunner (what bench.py's config-3 entry and batch.demodulate_sharded run): four targets of one
-    resident capture at the C2 rate -- two of them multi-group filters, one whose carrier sits on the other side so that
+    resident capture at the C2 rate -- two of them multi-group filters (2 and 5 tap-row groups), one whose carrier sits on the other side so that
     its probe overrules the speculative sign +1 -- every target's channel-rate audio and 48 kHz PCM16 against its own
     oracle chain; two captures back to back through the two buffer slots."""
     import torch
@@ -432,7 +432,7 @@ def test_resident_bank_runner_matches_the_oracle_per_target(A):
     devs = [D.to_device(c.reshape(-1), "int16") for c in caps]
     torch.cuda.synchronize()
     tickets = [runner.submit(x) for x in devs]
-    assert tickets[0]["launch"] == dict(lanes=1 + 1 + 2 + 1, launches=1, combines=1)  # 6401 / 8001 / 16385 (2 groups) / 6401 taps
+    assert tickets[0]["launch"] == dict(lanes=1 + 2 + 5 + 1, launches=1, combines=2)  # 6401 / 8001 / 28571 / 6401 taps at D = 104
     for cap, ticket in zip(caps, tickets):
         res = runner.collect(ticket)
         for spec, r in zip(targets, res):
