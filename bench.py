@@ -124,8 +124,17 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     ts = [runner.submit(raw, events=ev[i], enclosing=buf, lead_frames=0, resident=True) for i in range(steps)]
     res = [runner.collect(t) for t in ts][-1]
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt_eager = (time.perf_counter() - t0) / steps
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # the same step captured into a hipGraph per (buffer, slot) and replayed: one host call per capture
+    for t in [runner.submit_captured(raw, enclosing=buf, lead_frames=0) for _ in range(warm)]:
+        runner.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = [runner.submit_captured(raw, enclosing=buf, lead_frames=0) for _ in range(steps)]
+    res = [runner.collect(t) for t in ts][-1]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
     want = O.run_chain(host, sample_rate=fs, freq_offset=f_off, keep_decimated=False)
     audio = res["audio"].cpu().numpy()
     algo = (4.0 + 4.0 * 48_000.0 / fs) * n
@@ -133,6 +142,8 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
         "workload": "BASELINE config 1 (the reference's --benchmark capture): 5 s @ 2.5 MS/s int16 I/Q, 1 NFM channel, +25 kHz, "
                     f"bw 12.5 kHz, D={d}, {len(taps)} taps",
         "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
+        "step": "captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured)",
+        "ms_per_step_direct_launches": round(dt_eager * 1e3, 4),
         "roofline": {"kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                      "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},

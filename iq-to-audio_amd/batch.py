@@ -191,12 +191,84 @@ class ResidentCaptureRunner:
         slot["busy"] = ticket
         return ticket
 
+    # ---- captured steps (hipGraph) ------------------------------------------------------------------------------------
+    #
+    # A capture of a few tens of MB takes the GPU less time than the host needs to queue its dozen launches through
+    # Python (BASELINE config 1: channelizer 51 us of a 214 us step).  For a capture that sits in a FIXED device buffer
+    # the whole step -- both probes, the edge launch, the channelizer, the three demodulator launches, the resampler and
+    # the copy of the PCM16 into pinned memory -- is therefore captured once into a hipGraph (one stream, no events
+    # inside) and replayed with a single host call per capture.  The probes write their powers into a pinned slot that
+    # belongs to the graph; ``collect`` reads it after the replay has finished and, if it says -1, runs that capture
+    # again the ordinary way with the right sign.
+
+    def _captured_step(self, raw_dev, slot, halo):
+        """Queue the whole step for sign +1 on the current (capturing) stream; returns what collect needs."""
+        chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=self.override or 1, decimation=self.d,
+                           fmt=self.fmt, iq_order=self.iq_order)
+        chan.plan_ahead()
+        dem = slot["dem"]
+        probe = None
+        if self.override is None:
+            warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
+            probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order, record_done=False)
+        dem.reset()
+        dem.prepare(self.n_dec, self.starts)
+        chan.process(raw_dev, out_dev=slot["z"], last_block=True, halo=halo)
+        dem.process(slot["z"], self.starts, slot["audio"])
+        pcm = self.rs.process(slot["audio"], want="pcm16")
+        host = slot["pcm_host"]
+        N.call("iqa_trickle_copy", N.ptr(pcm), c_void_p(host.data_ptr()), c_int64(host.numel() * host.element_size()),
+               c_int32(self.egress_workgroups), N.stream_ptr())
+        return dict(chan=chan, dem=dem, pcm=pcm, probe=probe, kernel=chan._kernel.last_kernel)
+
+    def submit_captured(self, raw_dev, enclosing=None, lead_frames: int = 0) -> dict:
+        """``submit`` for a capture in a fixed buffer: the first call per (buffer, slot) runs the step once the ordinary way
+        (plans, tap uploads, pinned slots come into being), captures it into a graph and replays it; later calls replay.
+        Returns a ticket for ``collect``."""
+        torch = D.torch_mod()
+        if D.current_raw_stream() != self._compute_raw:
+            raise RuntimeError("submit_captured() must be called with the stream the runner was created on as the current stream")
+        index = self._next % self.SLOTS
+        slot = self.slots[index]
+        if slot["busy"] is not None:
+            self.collect(slot["busy"])
+        halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        key = (int(raw_dev.data_ptr()), index, None if enclosing is None else int(enclosing.data_ptr()), int(lead_frames))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        entry = graphs.get(key)
+        if entry is None:
+            # once the ordinary way, in this very slot: plans, tap uploads and the pinned probe slot exist afterwards
+            self.collect(self.submit(raw_dev, enclosing=enclosing, lead_frames=lead_frames))
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                parts = self._captured_step(raw_dev, slot, halo)
+            entry = graphs[key] = dict(graph=g, **parts)
+        else:
+            self._next += 1
+        entry["dem"].chunk_sumsq = entry["dem"].chunk_sumsq[-1:]  # (a replay re-runs the same demodulator call)
+        entry["graph"].replay()
+        done = torch.cuda.Event()
+        done.record()
+        ticket = dict(chan=entry["chan"], dem=entry["dem"], pcm=entry["pcm"], done=done, tail_done=done, kernel=entry["kernel"],
+                      slot=slot, egress_queued=True, resident=False, probe=None, graph_probe=entry["probe"],
+                      sign=self.override or 1, raw=raw_dev, halo=halo)
+        slot["busy"] = ticket
+        return ticket
+
     def collect(self, ticket: dict) -> dict:
         """Wait for a submitted capture.  Returns {"pcm_host", "sign", "demod" (``.peak``, ``.chunk_rms_dbfs()``),
         "audio", "z", "kernel"}; the buffers belong to the runner and are reused ``SLOTS`` submits later."""
         slot = ticket["slot"]
         if ticket.get("collected"):
             return ticket["result"]
+        if ticket.get("graph_probe") is not None:  # a replayed step: its probes' powers sit in the graph's pinned slot
+            ticket["done"].synchronize()
+            sign = ticket["graph_probe"].peek()
+            if sign != ticket["sign"]:  # the captured step assumed +1: this capture again, the ordinary way
+                redo = self._chain(ticket["raw"], slot, sign, None, ticket.get("halo"), False)
+                self._flush_egress()
+                ticket.update(redo, sign=sign, probe=None, raw=ticket["raw"], graph_probe=None)
         if D.current_raw_stream() != self._compute_raw:  # (it may queue the D2H, or the whole capture again)
             raise RuntimeError("collect() must be called with the stream the runner was created on as the current stream")
         sign = ticket["sign"]

@@ -445,21 +445,18 @@ __global__ __launch_bounds__(256) void k_mfma_combine(CombineArgs a)
     double2 d = a.part[0][i];
     for (int k = 1; k < a.n_parts; ++k) {  // in group order: the chained single-lane passes add them in this order too
         const double2 v = a.part[k][i];
-        d.x = v.x + d.x;
-        d.y = v.y + d.y;
+        d.x = __dadd_rn(v.x, d.x);
+        d.y = __dadd_rn(v.y, d.y);
     }
-    float my_re = static_cast<float>(d.x), my_im = static_cast<float>(d.y);
-    if (a.conj_sum) my_im = -my_im;
-    float yr = my_re, yi = my_im;
+    float cf = 1.f, sf = 0.f;
     if (a.rotate) {
         const unsigned long long ph = a.rot_base + static_cast<unsigned long long>(a.m_first + i) * a.rot_step;
         double sn, cs;
         sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &sn, &cs);
-        const float cf = static_cast<float>(cs), sf = static_cast<float>(sn);
-        yr = my_re * cf - my_im * sf;
-        yi = my_re * sf + my_im * cf;
+        cf = static_cast<float>(cs);
+        sf = static_cast<float>(sn);
     }
-    a.out[i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+    a.out[i] = mfma_finish(d.x, d.y, a.conj_sum, a.rotate, cf, sf, a.sc_re, a.sc_im);
 }
 }  // namespace iqa
 

@@ -164,26 +164,18 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
         v_im = static_cast<double>(si);
     }
     if (i >= 0 && i < c.cnt) {
-        double d_re = (v_re * 256.0 + a.c_re) * a.unit;
-        double d_im = (v_im * 256.0 + a.c_im) * a.unit;
+        double d_re = mfma_scaled_sum(v_re, a.c_re, a.unit);
+        double d_im = mfma_scaled_sum(v_im, a.c_im, a.unit);
         if (a.partial_in != nullptr) {
             const double2 pr = a.partial_in[c.i0 + i];
-            d_re += pr.x;
-            d_im += pr.y;
+            d_re = __dadd_rn(d_re, pr.x);
+            d_im = __dadd_rn(d_im, pr.y);
         }
         if (!a.finalize) {
             a.partial_out[c.i0 + i] = make_double2(d_re, d_im);
         } else {
-            float my_re = static_cast<float>(d_re);
-            float my_im = static_cast<float>(d_im);
-            if (a.conj_sum) my_im = -my_im;
-            float yr = my_re, yi = my_im;
-            if (a.rotate) {
-                const float cf = static_cast<float>(e.wc), sf = static_cast<float>(e.ws);
-                yr = my_re * cf - my_im * sf;
-                yi = my_re * sf + my_im * cf;
-            }
-            a.out[c.i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+            a.out[c.i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, static_cast<float>(e.wc), static_cast<float>(e.ws),
+                                          a.sc_re, a.sc_im);
         }
     }
     const double nc = e.wc * a.rot64_re - e.ws * a.rot64_im;
@@ -355,6 +347,18 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     for (int r = 0; r < c.rounds; ++r) {
         if (STREAM) ring_wait_and_barrier<KS, ROWS, U8>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
+        const bool pf = STREAM && (r + R - 1 < c.rounds);
+        const int pf_tile = 2 * (r + R - 1) + cp;
+        const int pf_slot = (slot == 0) ? R - 1 : slot - 1;  // the slot round r-1 has just left
+        // The refill of that slot goes out FIRST, all KS + 1 instructions of it, before this round's matrix work: at
+        // 13 k steps the ring holds two rounds only, so a DMA issued late in round r (one per k step, as this loop used
+        // to do) had to land before the barrier of round r + 1 -- its whole L2/HBM latency, ~1000 cycles of a ~2500-cycle
+        // round, stood exposed at every barrier (measured on the five-target launch: the matrix pipe 52 % busy with no
+        // bank conflict and the LDS 23 % busy).  Issued here, a refill has the whole round to land.
+        if (pf) {
+#pragma unroll
+            for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
+        }
         if (EMIT && r >= RG_EMIT_LAG) {
             asm volatile("" ::: "memory");
             ring_emit_group<ACC64>(a, c, em, r - RG_EMIT_LAG);  // see ring_loader for why these sums are final
@@ -364,17 +368,13 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             scatter(held_t, held1, held2);
             held_t = -1;
         }
-        const bool pf = STREAM && (r + R - 1 < c.rounds);
-        const int pf_tile = 2 * (r + R - 1) + cp;
-        const int pf_slot = (slot == 0) ? R - 1 : slot - 1;  // the slot round r-1 has just left
         const int t = 2 * r + cp;
         if (t < c.tiles) {
             const char *la = c.smem + (slot * 2 + cp) * SLOT + c.lane_off;
-            // PF is a compile-time copy of `pf`: the k loop stays one basic block.  An LDS-DMA is a store to LDS as
+            // An LDS-DMA is a store to LDS as
             // far as the compiler knows, so it never moves a ds_read above an earlier issue(): the data fragments
             // are read PD k steps ahead by hand, and a scheduling barrier per k step keeps them there.
-            auto tile_body = [&](auto pf_c) {
-                constexpr bool PF = decltype(pf_c)::value;
+            auto tile_body = [&]() {
                 constexpr int PD = KS < 2 ? KS : 2;
                 v16i_t acc1, acc2;
                 if constexpr (U8) {
@@ -417,7 +417,6 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                         dd[ks + PD][0] = *reinterpret_cast<const v4i_t *>(la + 64 * (ks + PD));
                         dd[ks + PD][1] = *reinterpret_cast<const v4i_t *>(la + 64 * (ks + PD) + 16);
                     }
-                    if (PF) issue(pf_tile, pf_slot, ks);
                     if (DBG & 32) {
                         asm volatile("" ::"v"(hi), "v"(lo));
                     } else {
@@ -427,7 +426,6 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (PF) issue(pf_tile, pf_slot, KS);
                 }
                 if (DBG & 32) acc1 = acc2 = zero16;
                 if (DBG & 1) {
@@ -440,11 +438,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     scatter(t, acc1, acc2);
                 }
             };
-            if (pf) tile_body(std::true_type{});
-            else tile_body(std::false_type{});
-        } else if (pf) {
-#pragma unroll
-            for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
+            tile_body();
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }

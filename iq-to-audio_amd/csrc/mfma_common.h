@@ -36,6 +36,27 @@ struct MfmaArgs {
     double rot64_re, rot64_im;  // exp(j*2*pi*64*rot_step): rotation between outputs 64 apart (ring kernel emission)
 };
 
+// The last steps of every matrix-core emission, written with explicit roundings so that the kernels that share them
+// (per-lane kernel, ring kernels, the combine kernel of the multi-lane path) give the SAME bits for the same sums --
+// left to the compiler, `a*b + c*d` contracts to an fma in one kernel and not in another.
+__device__ __forceinline__ double mfma_scaled_sum(double v, double c, double unit)  // (256 v + c) * unit
+{
+    return __dmul_rn(__fma_rn(v, 256.0, c), unit);
+}
+__device__ __forceinline__ float2 mfma_finish(double d_re, double d_im, int conj_sum, int rotate, float cf, float sf, float sc_re,
+                                              float sc_im)
+{
+    const float my_re = static_cast<float>(d_re);
+    float my_im = static_cast<float>(d_im);
+    if (conj_sum) my_im = -my_im;
+    float yr = my_re, yi = my_im;
+    if (rotate) {
+        yr = __fmaf_rn(my_re, cf, -__fmul_rn(my_im, sf));
+        yi = __fmaf_rn(my_re, sf, __fmul_rn(my_im, cf));
+    }
+    return make_float2(__fmaf_rn(yr, sc_re, -__fmul_rn(yi, sc_im)), __fmaf_rn(yr, sc_im, __fmul_rn(yi, sc_re)));
+}
+
 // emission shared by both kernels: output m0+i sits at position 64+i of the S1/S2 arrays
 template <int THREADS>
 __device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, int acc_len, int cnt, long long i0,
@@ -45,32 +66,28 @@ __device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, i
         const int pos = MF_Q + i;
         const double s1r = s_acc[pos], s1i = s_acc[acc_len + pos];
         const double s2r = s_acc[2 * acc_len + pos], s2i = s_acc[3 * acc_len + pos];
-        double d_re = (s1r * 65536.0 + s2r * 256.0 + a.c_re) * a.unit;
-        double d_im = (s1i * 65536.0 + s2i * 256.0 + a.c_im) * a.unit;
+        double d_re = mfma_scaled_sum(s1r * 256.0 + s2r, a.c_re, a.unit);  // (65536 S1 + 256 S2 + c) * unit, exact up to the product
+        double d_im = mfma_scaled_sum(s1i * 256.0 + s2i, a.c_im, a.unit);
         if (a.partial_in != nullptr) {
             const double2 pr = a.partial_in[i0 + i];
-            d_re += pr.x;
-            d_im += pr.y;
+            d_re = __dadd_rn(d_re, pr.x);
+            d_im = __dadd_rn(d_im, pr.y);
         }
         if (!a.finalize) {
             a.partial_out[i0 + i] = make_double2(d_re, d_im);
             continue;
         }
-        float my_re = static_cast<float>(d_re);
-        float my_im = static_cast<float>(d_im);
-        if (a.conj_sum) my_im = -my_im;
-        float yr = my_re, yi = my_im;
+        float cf = 1.f, sf = 0.f;
         if (a.rotate) {
             const unsigned long long m = static_cast<unsigned long long>(m0 + i);
             const unsigned long long ph = a.rot_base + m * a.rot_step;
             const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
             double s, c;
             sincospi(2.0 * frac, &s, &c);
-            const float cf = static_cast<float>(c), sf = static_cast<float>(s);
-            yr = my_re * cf - my_im * sf;
-            yi = my_re * sf + my_im * cf;
+            cf = static_cast<float>(c);
+            sf = static_cast<float>(s);
         }
-        a.out[i0 + i] = make_float2(yr * a.sc_re - yi * a.sc_im, yr * a.sc_im + yi * a.sc_re);
+        a.out[i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, cf, sf, a.sc_re, a.sc_im);
     }
 }
 

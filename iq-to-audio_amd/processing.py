@@ -735,16 +735,24 @@ class MixSignProbe:
             return 1
         if self._sign is None:
             self._wait()
-            host = self._host.numpy()
-            best_sign, best_power = 1, -np.inf
-            for i, sign in enumerate((1, -1)):
-                power = float(host[i]) if self._valid[i] else -np.inf
-                if power > best_power:
-                    best_power, best_sign = power, sign
-            self._sign = best_sign
+            self._sign = self._decide()
             _release_scalars(self._host)
             self._host = None
         return self._sign
+
+    def _decide(self) -> int:
+        host = self._host.numpy()
+        best_sign, best_power = 1, -np.inf
+        for i, sign in enumerate((1, -1)):
+            power = float(host[i]) if self._valid[i] else -np.inf
+            if power > best_power:
+                best_power, best_sign = power, sign
+        return best_sign
+
+    def peek(self) -> int:
+        """The sign the two powers in the pinned slot say NOW, without giving the slot back: for probes that live inside
+        a captured graph (every replay writes the same slot again; the caller has waited for the replay)."""
+        return 1 if self._powers is None else self._decide()
 
     def _wait(self) -> None:
         done = self._done
