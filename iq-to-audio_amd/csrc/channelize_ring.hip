@@ -758,13 +758,23 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
         set_error("row-staged ring kernel: %d k steps per pass not instantiated (1..%d)", a.ksteps, RG_ROWS_MAX_KS);
         return IQA_EINVAL;
     }
-    if (dbg && a.ksteps == 7 && !acc64) {  // diagnostic instantiations exist for the benchmark shape only
+    if (dbg && a.ksteps == 7 && !acc64) {  // diagnostic instantiations exist for the two benchmark shapes only
         switch (dbg) {
             case 1: return ring_launch_one<7, 1, false>(a, blocks, lds, stream);
             case 16: return ring_launch_one<7, 16, false>(a, blocks, lds, stream);
             case 17: return ring_launch_one<7, 17, false>(a, blocks, lds, stream);
             case 32: return ring_launch_one<7, 32, false>(a, blocks, lds, stream);
             case 33: return ring_launch_one<7, 33, false>(a, blocks, lds, stream);
+            default: break;
+        }
+    }
+    if (dbg && a.ksteps == 13 && !acc64) {  // (D = 208: BASELINE configs 3 and 4, the kernel without loader waves)
+        switch (dbg) {
+            case 1: return ring_launch_one<13, 1, false>(a, blocks, lds, stream);
+            case 16: return ring_launch_one<13, 16, false>(a, blocks, lds, stream);
+            case 17: return ring_launch_one<13, 17, false>(a, blocks, lds, stream);
+            case 32: return ring_launch_one<13, 32, false>(a, blocks, lds, stream);
+            case 33: return ring_launch_one<13, 33, false>(a, blocks, lds, stream);
             default: break;
         }
     }

@@ -1,5 +1,5 @@
 """Ring-kernel ablations in the SUSTAINED (power-limited) regime: every variant runs N back-to-back launches and the
-median of the second half is reported, together with rocm-smi's clock/power at that point.  Debug bits (KS = 7, int32
+median of the second half is reported, together with rocm-smi's clock/power at that point.  Debug bits (KS = 7 or, with FS=20e6, 13; int32
 sums): 1 = no scatter, 16 = no DMA, 32 = no matrix work.  Usage: python profiles/sustained_ablation.py [N]"""
 import re, subprocess, sys
 from pathlib import Path
@@ -14,8 +14,9 @@ from iq_to_audio_amd import _dev as D, processing as PR
 from iq_to_audio_amd.benchmark import synthetic_iq_s16
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-fs, d, bw, f_off = 10e6, 104, 12500., 25e3
-n_total = 600_000_000
+fs = float(os.environ.get("FS", "10e6"))  # 10e6: D = 104, 7 k steps (config 2); 20e6: D = 208, 13 k steps (configs 3, 4)
+d, bw, f_off = int(round(fs / 96153.846)), 12500., 25e3
+n_total = int(fs * 60)
 host = synthetic_iq_s16(fs, 1.0, f_off).reshape(-1)
 raw = torch.from_numpy(host).to("cuda").repeat(60)[: 2 * n_total].contiguous()
 taps = A.design_channel_filter(fs, bw, d)

@@ -491,3 +491,73 @@ def test_captured_step_replays_to_the_same_audio(A):
     ref48 = O.float_to_pcm16(O.resample_48k(ref.audio, ref.fs_channel))
     assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
     assert abs(r["demod"].peak - ref.audio_peak) < 1e-5 and len(r["demod"].chunk_rms_dbfs()) == len(ref.rms_dbfs)
+
+
+# ---- dynamic range: a full-scale interferer beside an empty channel and beside a weak one ----------
+
+
+def test_stop_band_leakage_and_weak_channel_by_kernel_precision(A):
+    """What the fixed-point channelizers do to a channel that holds (almost) nothing while the capture is full scale.
+
+    Capture (10 MS/s, D = 104, 6401 taps, 0.4 s): a 0.95-of-full-scale tone at +1.3 MHz, an NFM signal at -70 dBFS
+    (3.16e-4) at +1.0 MHz -- 300 kHz beside the tone -- and one LSB of noise.  Channel E ("empty") is centred at +1.6 MHz:
+    300 kHz on the other side of the tone, nothing in it but the tone's leakage through the reference's own 80 dB Kaiser
+    filter.  Channel W ("weak") is the -70 dBFS signal.  Every kernel form against the oracle:
+
+      float32 VALU kernel | per-lane int8-MFMA, 16-bit taps | ring, 64-bit sums, 16-bit taps | ring, int32 sums, ~14-bit taps (default)
+
+    The tap quantisation error is ABSOLUTE -- a fraction of the wideband level, here the 0.95 tone -- whatever the
+    channel holds: the asserted bounds are per kernel form, the measured figures are printed for
+    DESIGN.md section 5, and the weak channel's NFM audio shows what each form leaves of a signal 70 dB below full scale.
+    """
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import processing as PR
+
+    fs, d, n = 10e6, 104, 4_000_000
+    t = np.arange(n, dtype=np.float64) / fs
+    f_tone, f_weak, f_empty = 1.3e6, 1.0e6, 1.6e6
+    msg = np.sin(2 * np.pi * 1000.0 * t)
+    weak = 10 ** (-70 / 20) * np.exp(1j * (2 * np.pi * f_weak * t + 3.0 * (1.0 - np.cos(2 * np.pi * 1000.0 * t))))
+    x = 0.95 * np.exp(2j * np.pi * f_tone * t) + weak
+    rng = np.random.default_rng(8)
+    iq = np.column_stack((x.real, x.imag)) + rng.normal(scale=1.0 / 32768.0, size=(n, 2))
+    raw = np.rint(np.clip(iq, -0.999, 0.999) * 32767.0).astype(np.int16).reshape(-1)
+    del msg
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    dev = D.to_device(raw, "int16")
+    forms = [("float32 VALU", dict(use_mfma=False, mfma_variant="ring", ring_acc32=True)),
+             ("per-lane MFMA, 16-bit taps", dict(use_mfma=True, mfma_variant="plain", ring_acc32=True)),
+             ("ring, 64-bit sums, 16-bit taps", dict(use_mfma=True, mfma_variant="ring", ring_acc32=False)),
+             ("ring, int32 sums, ~14-bit taps", dict(use_mfma=True, mfma_variant="ring", ring_acc32=True))]
+    keep = {k: getattr(PR._ChannelKernel, k) for k in ("use_mfma", "mfma_variant", "ring_acc32", "mfma_min_outputs")}
+    rows = {}
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 4096
+        for ch_name, f_c, mode in (("empty", f_empty, "am"), ("weak", f_weak, "nfm")):
+            x64 = O.ingest_to_complex64(raw, "s16")
+            z_ref = O.decimate(O.overlap_save(O.nco_mix(x64, O.NcoState(f_c, fs), 1), O.OverlapSaveState(taps, 65536)), O.DecimState(d))
+            settled = slice(200, None)  # past the filter's start-up
+            a_ref = np.clip(O.demodulate(z_ref, O.DemodState(mode, fs / d))[0], -0.99, 0.99)
+            level = 20 * np.log10(rms(z_ref[settled]) + 1e-30)
+            for name, flags in forms:
+                for k, v in flags.items():
+                    setattr(PR._ChannelKernel, k, v)
+                PR._KERNEL_CACHE.clear()
+                chz = A.Channelizer(taps, sample_rate=fs, freq_offset=f_c, mix_sign=1, decimation=d)
+                z = chz.process(dev).cpu().numpy()
+                a_gpu = np.clip(O.demodulate(z, O.DemodState(mode, fs / d))[0], -0.99, 0.99)  # the SAME (oracle) demodulator on both
+                rows[(ch_name, name)] = (level, rms((z - z_ref)[settled]), rms((a_gpu - a_ref)[settled]), chz._kernel.last_kernel)
+    finally:
+        for k, v in keep.items():
+            setattr(PR._ChannelKernel, k, v)
+        PR._KERNEL_CACHE.clear()
+    for (ch_name, name), (level, dz, da, kern) in rows.items():
+        print(f"dynamic range, {ch_name:5s} channel ({level:7.1f} dBFS in the oracle) | {name:32s} {kern:28s}: z rms err {dz:.2e} "
+              f"({20 * np.log10(dz + 1e-30):6.1f} dBFS), audio rms err {da:.2e}")
+    for ch_name in ("empty", "weak"):
+        assert rows[(ch_name, "float32 VALU")][1] < 3e-7
+        assert rows[(ch_name, "per-lane MFMA, 16-bit taps")][1] < 5e-6
+        assert rows[(ch_name, "ring, 64-bit sums, 16-bit taps")][1] < 5e-6
+        assert rows[(ch_name, "ring, int32 sums, ~14-bit taps")][1] < 4e-5
+        assert rows[(ch_name, "ring, int32 sums, ~14-bit taps")][3].endswith("_ring") and rows[(ch_name, "float32 VALU")][3] == "k_channelize_v1"
+    assert rows[("weak", "float32 VALU")][2] < 1e-4  # the float32 kernel holds the north-star bar 70 dB below full scale
