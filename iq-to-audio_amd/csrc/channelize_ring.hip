@@ -32,6 +32,13 @@
 #ifndef IQA_RING_DMA_AUX
 #define IQA_RING_DMA_AUX 0
 #endif
+// 1: a scheduling barrier behind every k step of the multiplying loop (what the loop needed while it also issued one
+// LDS-DMA per k step: the compiler will not move a ds_read across a DMA).  The refills now go out in front of the loop,
+// and the compiler's own interleaving of fragment reads, byte splits and MFMAs is faster: probe/kstep_probe.hip measures
+// 1483 ns per tile pair and SIMD against 1842 ns with the barriers (13 k steps, two waves per SIMD, no DMA, no scatter).
+#ifndef IQA_RING_SCHED_BARRIER
+#define IQA_RING_SCHED_BARRIER 0
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -371,9 +378,8 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         const int t = 2 * r + cp;
         if (t < c.tiles) {
             const char *la = c.smem + (slot * 2 + cp) * SLOT + c.lane_off;
-            // An LDS-DMA is a store to LDS as
-            // far as the compiler knows, so it never moves a ds_read above an earlier issue(): the data fragments
-            // are read PD k steps ahead by hand, and a scheduling barrier per k step keeps them there.
+            // The data fragments are read PD k steps ahead by hand (an LDS-DMA is a store to LDS as far as the compiler knows,
+            // so it never moves a ds_read above an earlier issue(): the refill in front of this loop is a fence for them).
             auto tile_body = [&]() {
                 constexpr int PD = KS < 2 ? KS : 2;
                 v16i_t acc1, acc2;
@@ -392,7 +398,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                         if (ks + PD < KS) du[ks + PD] = *reinterpret_cast<const v4i_t *>(la + 32 * (ks + PD));
                         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], v, ks ? acc1 : zero16, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], v, ks ? acc2 : zero16, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (IQA_RING_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
                 v4i_t dd[KS][2];
@@ -424,7 +430,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                         acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], lo, ks ? acc2 : zero16, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (IQA_RING_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
                 }
                 }
                 if (DBG & 32) acc1 = acc2 = zero16;
