@@ -39,6 +39,15 @@
 #ifndef IQA_RING_SCHED_BARRIER
 #define IQA_RING_SCHED_BARRIER 0
 #endif
+// 1: in the kernels without loader waves (9..16 k steps: D = 132..256) the two column-tile parities run HALF A ROUND
+// apart: two workgroup barriers per round, each the tile boundary of one parity and a mid-tile barrier of the other.
+// A SIMD holds one wave of each parity; with one barrier per round both reach their tile boundary -- results out of the
+// matrix pipe, 16 LDS adds, the barrier, the first fragment reads of the next tile -- at the same time and the matrix
+// pipe idles for that long; half a round apart, one of them is always in the middle of its 3*KS MFMAs (one wave alone
+// keeps the pipe 96 % busy: probe/kstep_probe.hip).  Build-time knob for A/B measurements only.
+#ifndef IQA_RING_STAGGER
+#define IQA_RING_STAGGER 1
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -348,9 +357,15 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             }
         }
     };
-    v16i_t held1 = zero16, held2 = zero16;  // DEFER: the previous tile's sums, scattered at the start of the next round
+    // STAGGER (see IQA_RING_STAGGER): barrier 2r is the tile boundary of parity 0's round r and falls into the middle of
+    // parity 1's tile of round r - 1; barrier 2r + 1 is parity 1's boundary and parity 0's mid-tile barrier.  Every wave
+    // executes the same 2 * rounds + 1 barriers: parity 1 one in front of its loop, parity 0 one behind it.
+    constexpr bool STAGGER = (IQA_RING_STAGGER != 0) && !G::LOADERS;
+    constexpr bool DEFER_ADDS = DEFER && !STAGGER;  // (the older, weaker way of keeping a SIMD's two waves out of step)
+    v16i_t held1 = zero16, held2 = zero16;  // DEFER_ADDS: the previous tile's sums, scattered at the start of the next round
     int held_t = -1;
     int slot = 0;
+    if (STAGGER && cp == 1) asm volatile("s_barrier" ::: "memory");
     for (int r = 0; r < c.rounds; ++r) {
         if (STREAM) ring_wait_and_barrier<KS, ROWS, U8>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
@@ -371,7 +386,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             ring_emit_group<ACC64>(a, c, em, r - RG_EMIT_LAG);  // see ring_loader for why these sums are final
             asm volatile("" ::: "memory");
         }
-        if (DEFER && held_t >= 0) {
+        if (DEFER_ADDS && held_t >= 0) {
             scatter(held_t, held1, held2);
             held_t = -1;
         }
@@ -409,6 +424,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
+                    if (STAGGER && ks == KS / 2) asm volatile("s_barrier" ::: "memory");  // the other parity's tile boundary
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
                     v4i_t hi, lo;
                     hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
@@ -436,7 +452,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 if (DBG & 32) acc1 = acc2 = zero16;
                 if (DBG & 1) {
                     asm volatile("" ::"v"(acc1), "v"(acc2));
-                } else if (DEFER) {
+                } else if (DEFER_ADDS) {
                     held1 = acc1;
                     held2 = acc2;
                     held_t = t;
@@ -445,10 +461,13 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 }
             };
             tile_body();
+        } else if (STAGGER) {
+            asm volatile("s_barrier" ::: "memory");  // no tile this round (the last round of an odd tile count): the mid-tile barrier alone
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
-    if (DEFER && held_t >= 0) scatter(held_t, held1, held2);
+    if (DEFER_ADDS && held_t >= 0) scatter(held_t, held1, held2);
+    if (STAGGER && cp == 0) asm volatile("s_barrier" ::: "memory");
     // the last groups: everything has landed behind a full wait and one more barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (EMIT) {

@@ -131,7 +131,7 @@ static void run(const v4i *taps, int *sink, unsigned long long *cyc, int tiles)
 // ---- more tap rows per wave: RT row tiles (32 rows each) share every data fragment a wave reads and splits ----------
 // WAVES = 8: two waves per SIMD (<= 256 registers each); WAVES = 4: one wave per SIMD (<= 512).
 template <int KSX, int RT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 1) void k_probe_rt(const v4i *taps, int *sink, int tiles)
+__global__ __launch_bounds__(WAVES * 64, 1) void k_probe_rt(const v4i *taps, int *sink, int tiles, unsigned long long *clk)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PITCHX = (4 * KSX + 1) * 16;
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_probe_rt(const v4i *taps, int
     v16i acc1[RT], acc2[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc1[rt] = acc2[rt] = zero16;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int t = 0; t < tiles; ++t) {
         v4i dd[KSX][2];
 #pragma unroll
@@ -182,16 +183,21 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_probe_rt(const v4i *taps, int
             }
         }
     }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     int s = 0;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += acc1[rt][q] + acc2[rt][q];
     if (s == 0x12345678) sink[0] = s;
+    if (tid == 0 && blockIdx.x == 100) {
+        clk[0] = c1 - c0;
+        clk[1] = r1 - r0;
+    }
 }
 
 template <int KSX, int RT, int WAVES>
-static void run_rt(const v4i *taps, int *sink, int tiles)
+static void run_rt(const v4i *taps, int *sink, int tiles, unsigned long long *clk)
 {
     const size_t lds = 32 * ((4 * KSX + 1) * 16) + 4096 + 1024;
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_rt<KSX, RT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -200,17 +206,19 @@ static void run_rt(const v4i *taps, int *sink, int tiles)
     hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_probe_rt<KSX, RT, WAVES>), dim3(256), dim3(WAVES * 64), lds, 0, taps, sink, tiles);
+        hipLaunchKernelGGL((k_probe_rt<KSX, RT, WAVES>), dim3(256), dim3(WAVES * 64), lds, 0, taps, sink, tiles, clk);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
     }
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double mfma_per_simd = (WAVES / 4.0) * 3 * KSX * RT * tiles;
-    printf("k steps %2d, %d row tile(s) per wave, %d wave(s) per SIMD: %8.3f ms; matrix pipe busy %.1f %% at 2.4 GHz (%.1f %% at 2.0 GHz); "
+    unsigned long long h[2];
+    hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double ghz = double(h[0]) / double(h[1]) * 0.1;  // in-kernel clock: s_memtime ticks per 100 MHz s_memrealtime tick
+    printf("k steps %2d, %d row tile(s) per wave, %d wave(s) per SIMD: %8.3f ms; in-kernel clock %.3f GHz -> matrix pipe busy %.1f %%; "
            "%.1f ns per 128 tap rows x 32 data rows per CU\n",
-           KSX, RT, WAVES / 4, ms, 100.0 * mfma_per_simd * 32 / (ms * 1e3 * 2400.0), 100.0 * mfma_per_simd * 32 / (ms * 1e3 * 2000.0),
-           ms * 1e6 / tiles / (WAVES * RT / 4.0));
+           KSX, RT, WAVES / 4, ms, ghz, 100.0 * mfma_per_simd * 32 / (ms * 1e6 * ghz), ms * 1e6 / tiles / (WAVES * RT / 4.0));
 }
 
 int main(int argc, char **argv)
@@ -237,12 +245,12 @@ int main(int argc, char **argv)
     run<2, 16>(taps, sink, cyc, tiles);
     run<2, 3>(taps, sink, cyc, tiles);
     run<2, 5>(taps, sink, cyc, tiles);
-    run_rt<13, 1, 8>(taps, sink, tiles);
-    run_rt<13, 2, 4>(taps, sink, tiles);
-    run_rt<13, 1, 4>(taps, sink, tiles);
-    run_rt<7, 1, 8>(taps, sink, tiles);
-    run_rt<7, 2, 8>(taps, sink, tiles);
-    run_rt<7, 2, 4>(taps, sink, tiles);
-    run_rt<7, 4, 4>(taps, sink, tiles);
+    run_rt<13, 1, 8>(taps, sink, tiles, cyc);
+    run_rt<13, 2, 4>(taps, sink, tiles, cyc);
+    run_rt<13, 1, 4>(taps, sink, tiles, cyc);
+    run_rt<7, 1, 8>(taps, sink, tiles, cyc);
+    run_rt<7, 2, 8>(taps, sink, tiles, cyc);
+    run_rt<7, 2, 4>(taps, sink, tiles, cyc);
+    run_rt<7, 4, 4>(taps, sink, tiles, cyc);
     return 0;
 }
