@@ -142,13 +142,24 @@ struct RingEmit {
     double wc, ws;
 };
 
+// A group of 64 finished outputs leaves the window in two steps, so that the multiplying wave that also emits (the
+// kernels without loader waves) can put its own matrix work between them: `ring_emit_load` reads the sums out of the
+// window (and the partial sums of earlier passes out of memory) and clears the slots; `ring_emit_store` -- a dozen
+// k steps later, when those reads have long returned -- scales, rotates and stores.  Back to back they are the one-step
+// emission of the loader waves.  (Done in one piece at the top of a round, the chain LDS read -> wait -> float64 maths ->
+// store made the emitting wave ~500 cycles late for its tile, and seven waves waited for it at every barrier.)
+struct RingEmitRegs {
+    double v_re, v_im;  // 256*S1 + S2 per component
+    double2 pr;         // partial sums of the earlier passes (0 when there are none)
+    int i;              // output index inside the block
+};
+
 template <bool ACC64>
-__device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx &c, RingEmit &e, int k)
+__device__ __forceinline__ void ring_emit_load(const MfmaArgs &a, const RingCtx &c, int k, RingEmitRegs &g)
 {
     const int pos = 64 * k + 1 + c.lane;
-    const int i = pos - MF_Q;  // output index inside the block
+    g.i = pos - MF_Q;
     const int s = pos & (RG_W - 1);
-    double v_re, v_im;  // 256*S1 + S2 per component
     if constexpr (ACC64) {
         long long *acc = reinterpret_cast<long long *>(c.s_acc);
         long long sr = acc[s], si = acc[RG_AS + s];
@@ -163,8 +174,8 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
         // the adds were (S1 << 32) + sign-extended S2: the low word is S2 itself (|S2| < 2^31), the rest is S1
         const int s2r = static_cast<int>(sr), s2i = static_cast<int>(si);
         const long long s1r = (sr - s2r) >> 32, s1i = (si - s2i) >> 32;
-        v_re = static_cast<double>(s1r) * 256.0 + static_cast<double>(s2r);
-        v_im = static_cast<double>(s1i) * 256.0 + static_cast<double>(s2i);
+        g.v_re = static_cast<double>(s1r) * 256.0 + static_cast<double>(s2r);
+        g.v_im = static_cast<double>(s1i) * 256.0 + static_cast<double>(s2i);
     } else {
         int *acc = c.s_acc;
         int sr = acc[s], si = acc[RG_AS + s];
@@ -176,16 +187,22 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
         }
         acc[s] = 0;
         acc[RG_AS + s] = 0;
-        v_re = static_cast<double>(sr);
-        v_im = static_cast<double>(si);
+        g.v_re = static_cast<double>(sr);
+        g.v_im = static_cast<double>(si);
     }
+    g.pr = make_double2(0.0, 0.0);
+    if (a.partial_in != nullptr && g.i >= 0 && g.i < c.cnt) g.pr = a.partial_in[c.i0 + g.i];
+}
+
+__device__ __forceinline__ void ring_emit_store(const MfmaArgs &a, const RingCtx &c, RingEmit &e, const RingEmitRegs &g)
+{
+    const int i = g.i;
     if (i >= 0 && i < c.cnt) {
-        double d_re = mfma_scaled_sum(v_re, a.c_re, a.unit);
-        double d_im = mfma_scaled_sum(v_im, a.c_im, a.unit);
+        double d_re = mfma_scaled_sum(g.v_re, a.c_re, a.unit);
+        double d_im = mfma_scaled_sum(g.v_im, a.c_im, a.unit);
         if (a.partial_in != nullptr) {
-            const double2 pr = a.partial_in[c.i0 + i];
-            d_re = __dadd_rn(d_re, pr.x);
-            d_im = __dadd_rn(d_im, pr.y);
+            d_re = __dadd_rn(d_re, g.pr.x);
+            d_im = __dadd_rn(d_im, g.pr.y);
         }
         if (!a.finalize) {
             a.partial_out[c.i0 + i] = make_double2(d_re, d_im);
@@ -197,6 +214,14 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
     const double nc = e.wc * a.rot64_re - e.ws * a.rot64_im;
     e.ws = fma(e.wc, a.rot64_im, e.ws * a.rot64_re);
     e.wc = nc;
+}
+
+template <bool ACC64>
+__device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx &c, RingEmit &e, int k)
+{
+    RingEmitRegs g;
+    ring_emit_load<ACC64>(a, c, k, g);
+    ring_emit_store(a, c, e, g);
 }
 
 template <int KS, bool ROWS, bool U8>
@@ -381,9 +406,11 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
             for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
         }
-        if (EMIT && r >= RG_EMIT_LAG) {
+        const bool emit_now = EMIT && r >= RG_EMIT_LAG;
+        RingEmitRegs eg;
+        if (emit_now) {
             asm volatile("" ::: "memory");
-            ring_emit_group<ACC64>(a, c, em, r - RG_EMIT_LAG);  // see ring_loader for why these sums are final
+            ring_emit_load<ACC64>(a, c, r - RG_EMIT_LAG, eg);  // see ring_loader for why these sums are final
             asm volatile("" ::: "memory");
         }
         if (DEFER_ADDS && held_t >= 0) {
@@ -425,6 +452,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (STAGGER && ks == KS / 2) asm volatile("s_barrier" ::: "memory");  // the other parity's tile boundary
+                    if (EMIT && ks == KS - 3 && emit_now) ring_emit_store(a, c, em, eg);  // (its reads went out before k step 0)
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
                     v4i_t hi, lo;
                     hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
@@ -461,8 +489,9 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 }
             };
             tile_body();
-        } else if (STAGGER) {
-            asm volatile("s_barrier" ::: "memory");  // no tile this round (the last round of an odd tile count): the mid-tile barrier alone
+        } else {
+            if (STAGGER) asm volatile("s_barrier" ::: "memory");  // no tile this round (odd tile count): the mid-tile barrier alone
+            if (emit_now) ring_emit_store(a, c, em, eg);
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
