@@ -185,15 +185,20 @@ typedef struct {
     uint64_t rot_step, rot_base;        /* as in iqa_chan_params */
     float out_scale_re, out_scale_im;
     int32_t q_group, finalize, conj_sum, rotate;
+    int32_t raw_partials;       /* finalize == 0 and no partial_in: partial_out_dev is int32[2*n_out], the integer sums
+                                 * (256*S1 + S2 per component) themselves; iqa_mfma_combine scales them (raw_scale) */
+    int32_t reserved;
 } iqa_mfma_lane;
 int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
                               int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
                               const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
                               int64_t n_out, void *stream);
 /* z[m_first + i] = finish(sum_k partials_dev[k][i]): the float32 conversion, conjugation, rotation and scaling of the
- * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..8 buffers of double2[n_out]. */
-int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials, int64_t m_first,
-                     int64_t n_out, void *z_out_dev, void *stream);
+ * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..8 buffers of double2[n_out],
+ * or -- raw_scale != NULL -- of int32[2*n_out] written by lanes with raw_partials = 1; raw_scale is a HOST array of
+ * n_partials triples {unit, c_re, c_im} (the lane's own values), applied as (256*v + c)*unit before the sum. */
+int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials,
+                     const double *raw_scale, int64_t m_first, int64_t n_out, void *z_out_dev, void *stream);
 
 /* Copy the last L-1 frames of (hist | raw) into hist (handles n_frames < L-1 by shifting).
  * ref: OverlapSaveFIR.process state update, processing.py:341-345.

@@ -53,7 +53,7 @@ class MfmaLane(ctypes.Structure):
     _fields_ = [("afrag_dev", c_void_p), ("z_out_dev", c_void_p), ("partial_in_dev", c_void_p), ("partial_out_dev", c_void_p),
                 ("unit", c_double), ("c_re", c_double), ("c_im", c_double), ("rot_step", c_uint64), ("rot_base", c_uint64),
                 ("out_scale_re", c_float), ("out_scale_im", c_float), ("q_group", c_int32), ("finalize", c_int32),
-                ("conj_sum", c_int32), ("rotate", c_int32)]
+                ("conj_sum", c_int32), ("rotate", c_int32), ("raw_partials", c_int32), ("reserved", c_int32)]
 
 
 class DemodParams(ctypes.Structure):
@@ -78,8 +78,8 @@ _SIGNATURES = {
                                            c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "iqa_channelize_mfma_multi": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, ctypes.POINTER(MfmaLane), c_int32,
                                                  c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
-    "iqa_mfma_combine": (ctypes.c_int, [ctypes.POINTER(ChanParams), ctypes.POINTER(c_void_p), c_int32, c_int64, c_int64, c_void_p,
-                                        c_void_p]),
+    "iqa_mfma_combine": (ctypes.c_int, [ctypes.POINTER(ChanParams), ctypes.POINTER(c_void_p), c_int32, ctypes.POINTER(c_double),
+                                        c_int64, c_int64, c_void_p, c_void_p]),
     "iqa_history_update": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "iqa_oscillator_mix": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_int64, c_double, c_double, c_void_p, c_void_p]),
     "iqa_decimate": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p]),

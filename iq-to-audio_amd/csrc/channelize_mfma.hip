@@ -319,6 +319,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         a.rot64_re = std::cos(2.0 * M_PI * turns);
         a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
+    a.raw_partials = 0;
     if (ring) {
         return mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2, u8);
     }
@@ -421,6 +422,8 @@ extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_
         l.finalize = s.finalize;
         l.conj_sum = s.conj_sum;
         l.rotate = s.rotate;
+        l.raw_partials = (s.raw_partials != 0 && !s.finalize && !s.partial_in_dev) ? 1 : 0;
+        if (s.raw_partials && !l.raw_partials) return fail_inval("raw partials need finalize == 0 and no partial_in");
     }
     return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr);
 }
@@ -430,6 +433,8 @@ extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_
 namespace iqa {
 struct CombineArgs {
     const double2 *part[8];
+    double unit[8], c_re[8], c_im[8];  // raw != 0: part[k] holds int2 sums, scaled here exactly as the kernels' emission does
+    int raw;
     int n_parts;
     float2 *out;
     long long m_first, n_out;
@@ -442,9 +447,15 @@ __global__ __launch_bounds__(256) void k_mfma_combine(CombineArgs a)
 {
     const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= a.n_out) return;
-    double2 d = a.part[0][i];
+    auto part = [&](int k) -> double2 {
+        if (!a.raw) return a.part[k][i];
+        const int2 v = reinterpret_cast<const int2 *>(a.part[k])[i];
+        return make_double2(mfma_scaled_sum(static_cast<double>(v.x), a.c_re[k], a.unit[k]),
+                            mfma_scaled_sum(static_cast<double>(v.y), a.c_im[k], a.unit[k]));
+    };
+    double2 d = part(0);
     for (int k = 1; k < a.n_parts; ++k) {  // in group order: the chained single-lane passes add them in this order too
-        const double2 v = a.part[k][i];
+        const double2 v = part(k);
         d.x = __dadd_rn(v.x, d.x);
         d.y = __dadd_rn(v.y, d.y);
     }
@@ -460,8 +471,8 @@ __global__ __launch_bounds__(256) void k_mfma_combine(CombineArgs a)
 }
 }  // namespace iqa
 
-extern "C" int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials, int64_t m_first,
-                                int64_t n_out, void *z_out_dev, void *stream)
+extern "C" int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials,
+                                const double *raw_scale, int64_t m_first, int64_t n_out, void *z_out_dev, void *stream)
 {
     if (p == nullptr || partials_dev == nullptr) return fail_inval("params is NULL");
     if (n_partials < 1 || n_partials > 8) return fail_inval("1..8 partial buffers");
@@ -474,6 +485,12 @@ extern "C" int iqa_mfma_combine(const iqa_chan_params *p, const void *const *par
         a.part[k] = static_cast<const double2 *>(partials_dev[k]);
     }
     a.n_parts = n_partials;
+    a.raw = raw_scale != nullptr;
+    for (int k = 0; k < n_partials && raw_scale; ++k) {
+        a.unit[k] = raw_scale[3 * k];
+        a.c_re[k] = raw_scale[3 * k + 1];
+        a.c_im[k] = raw_scale[3 * k + 2];
+    }
     a.out = static_cast<float2 *>(z_out_dev);
     a.m_first = m_first;
     a.n_out = n_out;

@@ -44,9 +44,11 @@
 // A SIMD holds one wave of each parity; with one barrier per round both reach their tile boundary -- results out of the
 // matrix pipe, 16 LDS adds, the barrier, the first fragment reads of the next tile -- at the same time and the matrix
 // pipe idles for that long; half a round apart, one of them is always in the middle of its 3*KS MFMAs (one wave alone
-// keeps the pipe 96 % busy: probe/kstep_probe.hip).  Build-time knob for A/B measurements only.
+// keeps the pipe 96 % busy: probe/kstep_probe.hip).  MEASURED and left off: 9.48 against 9.15 ms on the five-target launch,
+// 1.057 against 1.055 ms on one channel at D = 208 -- tile boundaries are not what holds this kernel back (DESIGN.md
+// section 6).  Build-time knob for A/B measurements only.
 #ifndef IQA_RING_STAGGER
-#define IQA_RING_STAGGER 1
+#define IQA_RING_STAGGER 0
 #endif
 
 #include <atomic>
@@ -205,7 +207,10 @@ __device__ __forceinline__ void ring_emit_store(const MfmaArgs &a, const RingCtx
             d_im = __dadd_rn(d_im, g.pr.y);
         }
         if (!a.finalize) {
-            a.partial_out[c.i0 + i] = make_double2(d_re, d_im);
+            if (a.raw_partials)  // the integer sums themselves (exact: int32 by construction); iqa_mfma_combine scales them
+                reinterpret_cast<int2 *>(a.partial_out)[c.i0 + i] = make_int2(static_cast<int>(g.v_re), static_cast<int>(g.v_im));
+            else
+                a.partial_out[c.i0 + i] = make_double2(d_re, d_im);
         } else {
             a.out[c.i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, static_cast<float>(e.wc), static_cast<float>(e.ws),
                                           a.sc_re, a.sc_im);
@@ -625,7 +630,7 @@ struct RingLane {
     unsigned long long rot_step, rot_base;
     double rot64_re, rot64_im;
     float sc_re, sc_im;
-    int col_shift, finalize, conj_sum, rotate;
+    int col_shift, finalize, conj_sum, rotate, raw_partials;
 };
 
 constexpr int RG_MAX_LANES = 16;  // (<= 5 targets x <= 3 tap-row groups in the reference's CLI; the table travels as kernel arguments)
@@ -661,6 +666,7 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
     a.finalize = l.finalize;
     a.conj_sum = l.conj_sum;
     a.rotate = l.rotate;
+    a.raw_partials = l.raw_partials;
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
     ring_block<KS, 0, false, ROWS, U8>(a, range_idx);
 }
@@ -885,6 +891,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         l.finalize = s.finalize;
         l.conj_sum = s.conj_sum;
         l.rotate = s.rotate;
+        l.raw_partials = s.raw_partials;
     }
     for (int i = n_lanes; i < RG_MAX_LANES; ++i) m.lane[i] = m.lane[0];
     const long long ranges = (a.n_out + a.range - 1) / a.range;

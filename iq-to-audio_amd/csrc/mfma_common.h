@@ -34,6 +34,7 @@ struct MfmaArgs {
     unsigned long long rot_step, rot_base;
     float sc_re, sc_im;
     double rot64_re, rot64_im;  // exp(j*2*pi*64*rot_step): rotation between outputs 64 apart (ring kernel emission)
+    int raw_partials;  // ring kernels, int32 sums, finalize == 0, no partial_in: partial_out holds int2 {256*S1+S2 re, im} (8 B per output)
 };
 
 // The last steps of every matrix-core emission, written with explicit roundings so that the kernels that share them
@@ -107,7 +108,7 @@ struct MfmaLane {
     unsigned long long rot_step, rot_base;
     double rot64_re, rot64_im;
     float sc_re, sc_im;
-    int col_shift, finalize, conj_sum, rotate;
+    int col_shift, finalize, conj_sum, rotate, raw_partials;
 };
 int mfma_ring_launch_multi(const MfmaArgs &common, const MfmaLane *lanes, int n_lanes, size_t lds_bytes, hipStream_t stream, bool rows,
                            bool u8, unsigned *blocks_out);

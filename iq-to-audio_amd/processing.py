@@ -598,7 +598,10 @@ class ChannelBank:
         kranges = [(ps.k_first, ps.k_count) for ps in plans[0].passes if ps.group == 0]
         ids = [(ci, gi) for ci, mp in enumerate(plans) for gi in range(len(mp.groups))]  # lane identities
         need_partial = {(ci, gi): (len(kranges) > 1 or len(plans[ci].groups) > 1) for ci, gi in ids}
-        partial = {key: D.empty(2 * n_int, "float64") for key, needed in need_partial.items() if needed}
+        # single k-step range: a tap-row group's partial sums travel as the exact int32 pairs (8 B per output) and the
+        # combine kernel scales them; chained k-step ranges hand double2 sums from pass to pass (16 B)
+        raw = len(kranges) == 1
+        partial = {key: D.empty(2 * n_int, "int32" if raw else "float64") for key, needed in need_partial.items() if needed}
         cpx = max(1, _ChannelKernel.launch_blocks // 8)  # CUs per XCD class the launch may fill
         launches = 0
         for lo in range(0, len(ids), self.MAX_LANES):
@@ -623,6 +626,7 @@ class ChannelBank:
                     lane.out_scale_re, lane.out_scale_im = k.params.out_scale_re, k.params.out_scale_im
                     lane.q_group, lane.finalize = gi, int(fin)
                     lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
+                    lane.raw_partials = int(raw and not fin)
                 N.call("iqa_channelize_mfma_multi", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first),
                        c_int32(k_count), c_int32(rng), table, c_int32(len(part)), N.ptr(big), c_int64(big_frames),
                        c_int64(big_consumed), c_int64(m_a), c_int64(n_int), N.stream_ptr())
@@ -631,8 +635,15 @@ class ChannelBank:
         for ci, mp in enumerate(plans):
             if len(mp.groups) > 1:
                 ptrs = (c_void_p * len(mp.groups))(*[partial[(ci, gi)].data_ptr() for gi in range(len(mp.groups))])
-                N.call("iqa_mfma_combine", byref(kernels[ci].params), ptrs, c_int32(len(mp.groups)), c_int64(m_a), c_int64(n_int),
-                       N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
+                scale = None
+                if raw:
+                    vals = []
+                    for gi in range(len(mp.groups)):
+                        ps = next(p_ for p_ in mp.passes if p_.group == gi)
+                        vals += [mp.groups[gi].unit / (256.0 if self.fmt == "u8" else 1.0), ps.c_re, ps.c_im]
+                    scale = (c_double * len(vals))(*vals)
+                N.call("iqa_mfma_combine", byref(kernels[ci].params), ptrs, c_int32(len(mp.groups)), scale, c_int64(m_a),
+                       c_int64(n_int), N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
                 combines += 1
         self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines)
         return zs
