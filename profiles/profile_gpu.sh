@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline"   # the defaults (100 warm-up + 1000 timed captures): the sustained, power-limited state of the judged run
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-extras"   # the defaults (100 warm-up + 1000 timed captures): the sustained, power-limited state of the judged run
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err" || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err" || exit 1
