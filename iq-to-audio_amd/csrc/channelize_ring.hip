@@ -156,7 +156,7 @@ struct RingEmitRegs {
     int i;              // output index inside the block
 };
 
-template <bool ACC64>
+template <bool ACC64, bool EARLY>
 __device__ __forceinline__ void ring_emit_load(const MfmaArgs &a, const RingCtx &c, int k, RingEmitRegs &g)
 {
     const int pos = 64 * k + 1 + c.lane;
@@ -193,9 +193,16 @@ __device__ __forceinline__ void ring_emit_load(const MfmaArgs &a, const RingCtx 
         g.v_im = static_cast<double>(si);
     }
     g.pr = make_double2(0.0, 0.0);
-    if (a.partial_in != nullptr && g.i >= 0 && g.i < c.cnt) g.pr = a.partial_in[c.i0 + g.i];
+    // EARLY: the earlier passes' partial sums are requested here, a dozen k steps before they are used (the emitting
+    // MULTIPLYING wave: it issues no LDS-DMAs, a wait for this load costs it nothing).  A loader wave must not: the wait
+    // for the load would be a vmcnt(0) in the middle of its counted DMA sequence -- the whole ring drained once per round
+    // (measured: 0.653 against 0.585 ms at D = 104).  It loads them where it uses them, inside the branch.
+    if constexpr (EARLY) {
+        if (a.partial_in != nullptr && g.i >= 0 && g.i < c.cnt) g.pr = a.partial_in[c.i0 + g.i];
+    }
 }
 
+template <bool EARLY>
 __device__ __forceinline__ void ring_emit_store(const MfmaArgs &a, const RingCtx &c, RingEmit &e, const RingEmitRegs &g)
 {
     const int i = g.i;
@@ -203,8 +210,9 @@ __device__ __forceinline__ void ring_emit_store(const MfmaArgs &a, const RingCtx
         double d_re = mfma_scaled_sum(g.v_re, a.c_re, a.unit);
         double d_im = mfma_scaled_sum(g.v_im, a.c_im, a.unit);
         if (a.partial_in != nullptr) {
-            d_re = __dadd_rn(d_re, g.pr.x);
-            d_im = __dadd_rn(d_im, g.pr.y);
+            const double2 pr = EARLY ? g.pr : a.partial_in[c.i0 + i];
+            d_re = __dadd_rn(d_re, pr.x);
+            d_im = __dadd_rn(d_im, pr.y);
         }
         if (!a.finalize) {
             if (a.raw_partials)  // the integer sums themselves (exact: int32 by construction); iqa_mfma_combine scales them
@@ -225,8 +233,8 @@ template <bool ACC64>
 __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx &c, RingEmit &e, int k)
 {
     RingEmitRegs g;
-    ring_emit_load<ACC64>(a, c, k, g);
-    ring_emit_store(a, c, e, g);
+    ring_emit_load<ACC64, false>(a, c, k, g);
+    ring_emit_store<false>(a, c, e, g);
 }
 
 template <int KS, bool ROWS, bool U8>
@@ -415,7 +423,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         RingEmitRegs eg;
         if (emit_now) {
             asm volatile("" ::: "memory");
-            ring_emit_load<ACC64>(a, c, r - RG_EMIT_LAG, eg);  // see ring_loader for why these sums are final
+            ring_emit_load<ACC64, true>(a, c, r - RG_EMIT_LAG, eg);  // see ring_loader for why these sums are final
             asm volatile("" ::: "memory");
         }
         if (DEFER_ADDS && held_t >= 0) {
@@ -457,7 +465,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (STAGGER && ks == KS / 2) asm volatile("s_barrier" ::: "memory");  // the other parity's tile boundary
-                    if (EMIT && ks == KS - 3 && emit_now) ring_emit_store(a, c, em, eg);  // (its reads went out before k step 0)
+                    if (EMIT && ks == KS - 3 && emit_now) ring_emit_store<true>(a, c, em, eg);  // (its reads went out before k step 0)
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
                     v4i_t hi, lo;
                     hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
@@ -496,7 +504,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             tile_body();
         } else {
             if (STAGGER) asm volatile("s_barrier" ::: "memory");  // no tile this round (odd tile count): the mid-tile barrier alone
-            if (emit_now) ring_emit_store(a, c, em, eg);
+            if (emit_now) ring_emit_store<true>(a, c, em, eg);
         }
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }

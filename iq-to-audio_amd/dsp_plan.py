@@ -193,6 +193,7 @@ class MfmaPlan:
     ksteps: int
     groups: list
     passes: list
+    err_norm: float = 0.0  # sqrt(sum_k |T_k u - g_k|^2) per unit of full scale: the z error for a white input of unit RMS
 
     # single-pass conveniences (tests, and the common ceil(L/D) <= 64, D <= 256 case)
     @property
@@ -262,6 +263,7 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
     D = plan.decimation
     n_groups = max(1, -(-(-(-plan.ntaps // D)) // MFMA_Q))
     groups, passes = [], []
+    err_sq = 0.0
     ksteps = -(-2 * D // 32)
     n_chunks = -(-ksteps // (max_ksteps or MFMA_MAX_KSTEPS_PER_PASS))  # k-step ranges: one pass each
     bounds = [round(i * ksteps / n_chunks) for i in range(n_chunks + 1)]
@@ -290,6 +292,7 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
             if bound < 2**31 - 1:
                 break
             unit *= max(1.02, bound / (2**31 - 1) * 1.001)
+        err_sq += 0.5 * float(((t * unit - a) ** 2).sum())  # every complex tap sits in the matrix twice (re and im rows)
         frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
         frag[:, :, 0] = q1.reshape(-1)[flat]
         frag[:, :, 1] = q2.reshape(-1)[flat]
@@ -301,7 +304,7 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
             bias = 128.0 if plan.fmt == "s16" else 0.0
             passes.append(MfmaPass(gi, k0, k1 - k0, bias * float(sl[:MFMA_Q].sum(dtype=np.int64)),
                                    bias * float(sl[MFMA_Q:].sum(dtype=np.int64))))
-    return MfmaPlan(ksteps, groups, passes)
+    return MfmaPlan(ksteps, groups, passes, math.sqrt(err_sq) / INGEST_SCALE[plan.fmt])
 
 
 def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decimation: int, ksteps: int,

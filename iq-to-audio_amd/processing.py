@@ -163,8 +163,9 @@ class _ChannelKernel:
     _VARIANT = {"plain": (0, 0), "ring": (64, 0)}  # flags, extra LDS bytes
     mfma_min_outputs = 32768
 
-    def __init__(self, plan: P.ChannelPlan):
+    def __init__(self, plan: P.ChannelPlan, exact: bool = False):
         self.plan = plan
+        self.exact = bool(exact)  # float32 kernel everywhere (the precision guard's choice for very weak channels)
         lpad = int(N.lib().iqa_taps_padded_len(plan.ntaps))
         if plan.taps_window.size != lpad:
             raise ValueError("tap window padding does not match the library")
@@ -188,7 +189,7 @@ class _ChannelKernel:
             self._ring_mode = int(N.lib().iqa_mfma_ring_mode(code, plan.decimation, 0, ks_all, acc32))
             if self._ring_mode == 0:
                 self._ring_mode = int(N.lib().iqa_mfma_ring_mode(code, plan.decimation, 0, min(ks_all, self.RING_ROWS_KSTEPS), acc32))
-        self._mfma_ok = bool(self.use_mfma and P.mfma_supported(plan) and (plan.fmt == "s16" or self._ring_mode == 2))
+        self._mfma_ok = bool(self.use_mfma and not self.exact and P.mfma_supported(plan) and (plan.fmt == "s16" or self._ring_mode == 2))
 
     def _ensure_mfma(self):
         with self._lock:
@@ -216,6 +217,11 @@ class _ChannelKernel:
                     c_im=ps.c_im, debug_stamps=None, q_group=ps.group, k_first=ps.k_first, k_count=ps.k_count,
                     finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
+
+    def fixed_point_error_norm(self) -> float:
+        """z error (RMS) of the fixed-point kernels per unit RMS of a white wideband input at full scale = 1: the 2-norm
+        of the tap quantisation error (0.0 when this channel never runs on the matrix cores)."""
+        return float(self._ensure_mfma().err_norm) if self._mfma_ok else 0.0
 
     def _range_max(self, k_count: int, variant: str) -> int:
         if variant == "ring":  # tap fragments in registers, sums in a sliding window: a block is not bounded by LDS
@@ -368,12 +374,12 @@ def immutable_taps(taps) -> np.ndarray:
 
 
 def _cached_kernel(taps: np.ndarray, *, sample_rate: float, freq_offset: float, mix_sign: int, decimation: int,
-                   fmt: str, iq_order: str):
+                   fmt: str, iq_order: str, exact: bool = False):
     """(plan, kernel) for this configuration, planned once per process and device."""
     taps = np.ascontiguousarray(taps)
     raw, raw_hash = _taps_fingerprint(taps)
     key = (raw_hash, taps.dtype.str, taps.shape, float(sample_rate), float(freq_offset), int(mix_sign), int(decimation),
-           fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, _ChannelKernel.ring_acc32,
+           fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, _ChannelKernel.ring_acc32, bool(exact),
            D.torch_mod().cuda.current_device())
     with _KERNEL_CACHE_LOCK:
         hit = _KERNEL_CACHE.get(key)
@@ -383,7 +389,7 @@ def _cached_kernel(taps: np.ndarray, *, sample_rate: float, freq_offset: float, 
     lpad = int(N.lib().iqa_taps_padded_len(len(taps)))
     plan = P.plan_channel(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
                           decimation=decimation, fmt=fmt, iq_order=iq_order, padded_len=lpad)
-    kernel = _ChannelKernel(plan)
+    kernel = _ChannelKernel(plan, exact)
     with _KERNEL_CACHE_LOCK:
         _KERNEL_CACHE[key] = (raw, plan, kernel)
         while len(_KERNEL_CACHE) > _KERNEL_CACHE_MAX:
@@ -478,9 +484,11 @@ class Channelizer:
     """
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, mix_sign: int, decimation: int,
-                 fmt: str = "s16", iq_order: str = "iq"):
+                 fmt: str = "s16", iq_order: str = "iq", exact: bool = False):
+        """``exact``: the float32 kernel for every output (no fixed-point matrix-core kernel): ~20x slower, error ~1e-8
+        of full scale instead of ~1e-6 .. 1e-5 -- what the pipeline's precision guard picks for very weak channels."""
         self.plan, self._kernel = _cached_kernel(taps, sample_rate=sample_rate, freq_offset=freq_offset,
-                                                 mix_sign=mix_sign, decimation=decimation, fmt=fmt, iq_order=iq_order)
+                                                 mix_sign=mix_sign, decimation=decimation, fmt=fmt, iq_order=iq_order, exact=exact)
         self.fmt = fmt
         self.decimation = int(decimation)
         self.ntaps = len(taps)
@@ -689,6 +697,7 @@ class MixSignProbe:
         """``record_done=False``: the caller sets ``_done`` to event(s) of its own that lie behind both probes (an
         event record between two kernels of a stream costs ~7 us on this part)."""
         self._powers = None
+        self.power = None
         self._valid = [False, False]
         x_all, n_in = _as_frames(warmup, fmt)
         if n_in == 0:
@@ -758,6 +767,7 @@ class MixSignProbe:
             power = float(host[i]) if self._valid[i] else -np.inf
             if power > best_power:
                 best_power, best_sign = power, sign
+        self.power = best_power if np.isfinite(best_power) else None  # mean |z|^2 of the chosen sign's probe
         return best_sign
 
     def peek(self) -> int:
@@ -1072,9 +1082,25 @@ class _Target:
         self.peak = 0.0
         self.output_path = cfg.output_path if cfg.output_path else owner._default_output_path(info)
 
-    def _channelizer(self, sign: int) -> Channelizer:
+    def _channelizer(self, sign: int, exact: bool = False) -> Channelizer:
         return Channelizer(self.taps, sample_rate=self.sample_rate, freq_offset=self.freq_offset, mix_sign=sign,
-                           decimation=self.decimation, fmt=self.info.fmt, iq_order=self.cfg.iq_order)
+                           decimation=self.decimation, fmt=self.info.fmt, iq_order=self.cfg.iq_order, exact=exact)
+
+    #: Precision guard.  The fixed-point channelizers' error is a fraction of the WIDEBAND level whatever the channel
+    #: holds (~ err_norm x wideband RMS, 1..5 x that on tonal captures), and the FM discriminator divides by the channel's
+    #: own level: audio error ~ 0.024 x error / |z|.  A channel whose probed level is below guard x err_norm x wideband RMS
+    #: is therefore channelized by the float32 kernel (measured: a -70 dBFS NFM signal beside a full-scale tone comes out
+    #: 2.8e-4 RMS off the reference through the default kernel, 1.7e-7 through the float32 one).  0 switches the guard off.
+    precision_guard = 1000.0
+
+    def _guard(self, probe_power, wideband_rms) -> bool:
+        """True when this channel should take the float32 kernel (NFM only: AM and SSB do not divide by |z|)."""
+        if not self.precision_guard or probe_power is None or wideband_rms is None or self.demod is None:
+            return False
+        if (self.cfg.demod_mode or "").lower() not in ("nfm", "fm"):
+            return False
+        norm = self.chan._kernel.fixed_point_error_norm()
+        return norm > 0.0 and math.sqrt(max(probe_power, 0.0)) < self.precision_guard * norm * wideband_rms
 
     def begin(self, warm) -> None:
         """Launch the mixer-sign probes (asynchronously) and plan the channelizer for the likely sign meanwhile."""
@@ -1087,12 +1113,17 @@ class _Target:
             self.chan = self._channelizer(1)
         self.chan.plan_ahead()
 
-    def settle(self) -> None:
+    def settle(self, wideband_rms=None) -> None:
         if self.sign_probe is not None:
             self.mix_sign = self.sign_probe.result()
+            power = self.sign_probe.power
             self.sign_probe = None
             if self.mix_sign != 1:
                 self.chan = self._channelizer(self.mix_sign)
+            if self._guard(power, wideband_rms):
+                LOG.info("Channel level %.1f dBFS against a wideband level of %.1f dBFS: float32 channelizer for this target.",
+                         10.0 * math.log10(max(power, 1e-30)), 20.0 * math.log10(max(wideband_rms, 1e-15)))
+                self.chan = self._channelizer(self.mix_sign, exact=True)
         LOG.info("Selected mixer sign %d based on warm-up snippet.", self.mix_sign)
         n_dec_total = -(-self.total // self.decimation)
         self.z_all = D.empty(n_dec_total, "complex64") if (self.pass_through or self.cfg.dump_iq_path) else None
@@ -1267,8 +1298,15 @@ class MultiChannelPipeline:
             _check_cancel("warm-up")
             for t in targets:  # all probes are enqueued before the first read-back
                 t.begin(warm)
+            # wideband level of the warm-up block as a fraction of full scale (for the precision guard)
+            wide = warm.view(D.torch_mod().float32) if info.fmt == "f32" else warm
+            wide = wide.to(D.torch_mod().float32)
+            if info.fmt == "u8":
+                wide = wide - 128.0
+            wideband_rms = float((wide * wide).mean().sqrt().item()) * math.sqrt(2.0) * P.INGEST_SCALE[info.fmt]
+            del wide
             for t in targets:
-                t.settle()
+                t.settle(wideband_rms)
             if cfg.probe_only:
                 tracker.advance("ingest", float(warm.numel() // 2))
                 return [ProcessingResult(rate_probe, center_freq, t.target_freq, t.freq_offset, t.decimation, t.fs_channel,
@@ -1277,8 +1315,8 @@ class MultiChannelPipeline:
             # channels that share a decimation share their pass over every block (ChannelBank); built after settle(),
             # which may have replaced a channelizer by the one for the other mixer sign
             banks = []
-            for dec in sorted({t.decimation for t in targets}):
-                members = [t for t in targets if t.decimation == dec]
+            for key in sorted({(t.decimation, t.chan._kernel.exact) for t in targets}):
+                members = [t for t in targets if (t.decimation, t.chan._kernel.exact) == key]  # (float32-guarded channels run alone)
                 banks.append((ChannelBank([t.chan for t in members]), members))
             self.banks = [b for b, _ in banks]
             done = 0
