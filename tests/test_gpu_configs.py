@@ -561,3 +561,35 @@ def test_stop_band_leakage_and_weak_channel_by_kernel_precision(A):
         assert rows[(ch_name, "ring, int32 sums, ~14-bit taps")][1] < 4e-5
         assert rows[(ch_name, "ring, int32 sums, ~14-bit taps")][3].endswith("_ring") and rows[(ch_name, "float32 VALU")][3] == "k_channelize_v1"
     assert rows[("weak", "float32 VALU")][2] < 1e-4  # the float32 kernel holds the north-star bar 70 dB below full scale
+
+
+def test_precision_guard_routes_a_very_weak_nfm_channel_to_the_float32_kernel(A, tmp_path):
+    """The pipeline's precision guard (processing._Target.precision_guard): the dynamic-range capture of the test above
+    (0.95 tone, an NFM signal at -70 dBFS 300 kHz beside it) as a file, two NFM targets in one run -- the weak signal and
+    the tone itself.  The weak channel's probed level is below guard x (tap quantisation norm) x (wideband RMS), so it
+    takes the float32 kernel and meets the north-star bar (1e-4) where the fixed-point kernel would be 2.8e-4 off; the
+    strong channel keeps the matrix-core kernel."""
+    from iq_to_audio_amd import iqio
+
+    fs, n, fc = 10e6, 4_000_000, 1.0e9
+    t = np.arange(n, dtype=np.float64) / fs
+    weak = 10 ** (-70 / 20) * np.exp(1j * (2 * np.pi * 1.0e6 * t + 3.0 * (1.0 - np.cos(2 * np.pi * 1000.0 * t))))
+    x = 0.95 * np.exp(2j * np.pi * 1.3e6 * t) + weak
+    iq = np.column_stack((x.real, x.imag)) + np.random.default_rng(8).normal(scale=1.0 / 32768.0, size=(n, 2))
+    raw = np.rint(np.clip(iq, -0.999, 0.999) * 32767.0).astype(np.int16)
+    path = tmp_path / "dyn_1000000000Hz.cs16"
+    path.write_bytes(raw.tobytes())
+    cfgs = [A.ProcessingConfig(in_path=path, target_freq=fc + off, demod_mode="nfm", input_sample_rate=fs,
+                               output_path=tmp_path / f"g{i}.wav") for i, off in enumerate((1.0e6, 1.3e6))]
+    multi = A.MultiChannelPipeline(cfgs)
+    for o in multi.owners:
+        o.keep_channel_audio = True
+    res = multi.run()
+    assert [o.channelizer_kernel for o in multi.owners] == ["k_channelize_v1", "k_channelize_mfma_s16_ring"]
+    for off, r, o in zip((1.0e6, 1.3e6), res, multi.owners):
+        want = O.run_chain(raw, sample_rate=fs, freq_offset=off, keep_decimated=False)
+        got = o.audio_fs_channel.cpu().numpy()
+        assert got.size == want.audio.size and r.mix_sign == want.mix_sign
+        err = rms(got - want.audio)
+        print(f"precision guard: target {off:+.0f} Hz through {o.channelizer_kernel}: audio rms err {err:.2e}")
+        assert err < 1e-4, (off, err)
