@@ -338,11 +338,6 @@ class ResidentBankRunner:
         return Channelizer(spec["taps"], sample_rate=self.fs, freq_offset=spec["freq_offset"], mix_sign=sign, decimation=self.d,
                            fmt=self.fmt, iq_order=self.iq_order)
 
-    def _side_streams(self) -> list:
-        if not getattr(self, "_sides", None):
-            self._sides = [D.torch_mod().cuda.Stream() for _ in self.targets]
-        return self._sides
-
     def _finish_target(self, per, raw_unused=None) -> None:
         """Demodulator + writer clip, 48 kHz PCM16, copy to the host: for one target's z."""
         dem = per["dem"]
@@ -373,20 +368,8 @@ class ResidentBankRunner:
         bank.process(raw_dev, outs=[p["z"] for p in slot["per"]], last_block=True, halo=halo)
         if events:
             events[1].record()
-        # the targets' demodulator / resampler / copy chains are short launches that do not fill the part: each runs on
-        # a stream of its own behind the channelizer pass, and the caller's stream joins them all
-        main = torch.cuda.current_stream()
-        fork = torch.cuda.Event()
-        fork.record(main)
-        for per, side in zip(slot["per"], self._side_streams()):
-            side.wait_event(fork)
-            with D.on_stream(side, main):
-                self._finish_target(per)
-                for key in ("z", "audio"):
-                    per[key].record_stream(side)
-                joined = torch.cuda.Event()
-                joined.record(side)
-            main.wait_event(joined)
+        for per in slot["per"]:
+            self._finish_target(per)
         done = torch.cuda.Event()
         done.record()
         ticket = dict(slot=slot, probes=probes, signs=signs, raw=raw_dev, halo=halo, done=done, launch=bank.last_launch,
