@@ -404,9 +404,21 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     int held_t = -1;
     int slot = 0;
     if (STAGGER && cp == 1) asm volatile("s_barrier" ::: "memory");
+    // DBG & 2 (diagnostic builds): per wave, cycles spent waiting in front of / at the round barrier and cycles between
+    // barriers, summed over the rounds -> a.stamps[(workgroup * 8 + wave) * 4 + {0: wait, 1: work, 2: rounds, 3: first tile stamp}]
+    unsigned long long st_wait = 0, st_work = 0, st_prev = 0;
     for (int r = 0; r < c.rounds; ++r) {
+        unsigned long long st0 = 0;
+        if (DBG & 2) {
+            st0 = __builtin_amdgcn_s_memtime();
+            if (r) st_work += st0 - st_prev;
+        }
         if (STREAM) ring_wait_and_barrier<KS, ROWS, U8>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
+        if (DBG & 2) {
+            st_prev = __builtin_amdgcn_s_memtime();
+            st_wait += st_prev - st0;
+        }
         const bool pf = STREAM && (r + R - 1 < c.rounds);
         const int pf_tile = 2 * (r + R - 1) + cp;
         const int pf_slot = (slot == 0) ? R - 1 : slot - 1;  // the slot round r-1 has just left
@@ -510,6 +522,12 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     }
     if (DEFER_ADDS && held_t >= 0) scatter(held_t, held1, held2);
     if (STAGGER && cp == 0) asm volatile("s_barrier" ::: "memory");
+    if ((DBG & 2) && a.stamps != nullptr && c.lane == 0) {
+        unsigned long long *o = a.stamps + (static_cast<size_t>(blockIdx.x) * RG_WAVES + (cp * 4 + rt)) * 4;
+        o[0] = st_wait;
+        o[1] = st_work + (__builtin_amdgcn_s_memtime() - st_prev);
+        o[2] = static_cast<unsigned long long>(c.rounds);
+    }
     // the last groups: everything has landed behind a full wait and one more barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (EMIT) {
@@ -802,7 +820,7 @@ size_t mfma_ring_lds_bytes(int ksteps, bool rows, bool u8)
 // debug bit 7 (128) selects the 32-bit sums (needs fragments from dsp_plan.plan_mfma(acc32=True))
 int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
 {
-    const int dbg = a.debug & (1 | 16 | 32);
+    const int dbg = a.debug & (1 | 2 | 16 | 32);
     const bool acc64 = !(a.debug & 128);
     if (u8) {
         switch (a.ksteps) {
@@ -843,6 +861,8 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
             case 17: return ring_launch_one<13, 17, false>(a, blocks, lds, stream);
             case 32: return ring_launch_one<13, 32, false>(a, blocks, lds, stream);
             case 33: return ring_launch_one<13, 33, false>(a, blocks, lds, stream);
+            case 2: return ring_launch_one<13, 2, false>(a, blocks, lds, stream);    // per-wave barrier-wait / work cycles
+            case 18: return ring_launch_one<13, 18, false>(a, blocks, lds, stream);  // the same without the DMA stream
             default: break;
         }
     }
