@@ -47,6 +47,9 @@
 // keeps the pipe 96 % busy: probe/kstep_probe.hip).  MEASURED and left off: 9.48 against 9.15 ms on the five-target launch,
 // 1.057 against 1.055 ms on one channel at D = 208 -- tile boundaries are not what holds this kernel back (DESIGN.md
 // section 6).  Build-time knob for A/B measurements only.
+#ifndef IQA_RING_LOADERS_MAX_KS
+#define IQA_RING_LOADERS_MAX_KS 13
+#endif
 #ifndef IQA_RING_STAGGER
 #define IQA_RING_STAGGER 0
 #endif
@@ -102,7 +105,7 @@ struct RingGeo {
     static constexpr bool PADDED = KS <= 13;  // contiguous slots: rows at an odd pitch in LDS (conflict-free fragment reads)
     static constexpr int NI = 2 * KS + 1;  // contiguous slots: 1 KiB DMA instructions per tile (32 rows at a padded pitch)
     static constexpr int SLOT = ROWS ? 32 * PITCH : 1024 * NI;
-    static constexpr bool LOADERS = ROWS || KS <= 8;  // two extra waves feed the ring and emit (needs <= 168 registers)
+    static constexpr bool LOADERS = ROWS || KS <= IQA_RING_LOADERS_MAX_KS;  // two extra waves feed the ring and emit (needs <= 168 registers)
     static constexpr int NDMA = ROWS ? 32 : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
     static constexpr int FIT = (160 * 1024 - RG_ACC_BYTES) / (2 * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
