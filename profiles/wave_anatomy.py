@@ -15,8 +15,8 @@ host = synthetic_iq_s16(fs, 1.0, f_off).reshape(-1)
 raw = torch.from_numpy(host).to("cuda").repeat(60)[: 2 * n_total].contiguous()
 taps = A.design_channel_filter(fs, 12500.0, d)
 z = D.empty(-(-n_total // d), "complex64")
-roles = {0: "rt0 cp0 (issues DMAs)", 1: "rt1 cp0 (issues DMAs)", 2: "rt2 cp0 (emits)", 3: "rt3 cp0", 4: "rt0 cp1", 5: "rt1 cp1",
-         6: "rt2 cp1 (issues DMAs)", 7: "rt3 cp1 (issues DMAs)"}
+roles = {w: f"rt{w & 3} cp{w >> 2}" for w in range(8)}  # (13 k steps: loader waves feed the ring and emit; builds without them --
+# IQA_RING_LOADERS_MAX_KS=8 -- have waves 0, 1, 6, 7 issue the DMAs and wave 2 emit)
 for dbg, name in ((2, "everything"), (18, "no DMA stream")):
     PR._KERNEL_CACHE.clear()
     ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d)
