@@ -50,6 +50,14 @@
 #ifndef IQA_RING_LOADERS_MAX_KS
 #define IQA_RING_LOADERS_MAX_KS 13
 #endif
+// A/B knobs for the waves' interplay on a SIMD (diagnostic builds): IQA_RING_DEFER 0 = parity-1 waves scatter their tile
+// right behind it like parity 0; IQA_RING_PRIO 1 = parity-1 waves run at raised priority (s_setprio 1), 2 = parity-0 waves.
+#ifndef IQA_RING_DEFER
+#define IQA_RING_DEFER 1
+#endif
+#ifndef IQA_RING_PRIO
+#define IQA_RING_PRIO 0
+#endif
 #ifndef IQA_RING_STAGGER
 #define IQA_RING_STAGGER 0
 #endif
@@ -402,11 +410,13 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     // parity 1's tile of round r - 1; barrier 2r + 1 is parity 1's boundary and parity 0's mid-tile barrier.  Every wave
     // executes the same 2 * rounds + 1 barriers: parity 1 one in front of its loop, parity 0 one behind it.
     constexpr bool STAGGER = (IQA_RING_STAGGER != 0) && !G::LOADERS;
-    constexpr bool DEFER_ADDS = DEFER && !STAGGER;  // (the older, weaker way of keeping a SIMD's two waves out of step)
+    constexpr bool DEFER_ADDS = DEFER && !STAGGER && (IQA_RING_DEFER != 0);  // (the older, weaker way of keeping a SIMD's two waves out of step)
     v16i_t held1 = zero16, held2 = zero16;  // DEFER_ADDS: the previous tile's sums, scattered at the start of the next round
     int held_t = -1;
     int slot = 0;
     if (STAGGER && cp == 1) asm volatile("s_barrier" ::: "memory");
+    if (IQA_RING_PRIO == 1 && cp == 1) asm volatile("s_setprio 1");
+    if (IQA_RING_PRIO == 2 && cp == 0) asm volatile("s_setprio 1");
     // DBG & 2 (diagnostic builds): per wave, cycles spent waiting in front of / at the round barrier and cycles between
     // barriers, summed over the rounds -> a.stamps[(workgroup * 8 + wave) * 4 + {0: wait, 1: work, 2: rounds, 3: first tile stamp}]
     unsigned long long st_wait = 0, st_work = 0, st_prev = 0;
@@ -479,7 +489,8 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (STAGGER && ks == KS / 2) asm volatile("s_barrier" ::: "memory");  // the other parity's tile boundary
+                    // the other parity's tile boundary: no memory clobber -- this wave's own fragment reads may move across it
+                    if (STAGGER && ks == KS / 2) asm volatile("s_barrier");
                     if (EMIT && ks == KS - 3 && emit_now) ring_emit_store<true>(a, c, em, eg);  // (its reads went out before k step 0)
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
                     v4i_t hi, lo;

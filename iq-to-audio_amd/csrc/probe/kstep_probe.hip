@@ -245,6 +245,8 @@ int main(int argc, char **argv)
     run<2, 16>(taps, sink, cyc, tiles);
     run<2, 3>(taps, sink, cyc, tiles);
     run<2, 5>(taps, sink, cyc, tiles);
+    run<3, 4>(taps, sink, cyc, tiles);  // barrier per tile, compiler's schedule
+    run<4, 4>(taps, sink, cyc, tiles);  // + scatter
     run_rt<13, 1, 8>(taps, sink, tiles, cyc);
     run_rt<13, 2, 4>(taps, sink, tiles, cyc);
     run_rt<13, 1, 4>(taps, sink, tiles, cyc);
