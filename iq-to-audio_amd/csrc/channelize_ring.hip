@@ -47,8 +47,12 @@
 // keeps the pipe 96 % busy: probe/kstep_probe.hip).  MEASURED and left off: 9.48 against 9.15 ms on the five-target launch,
 // 1.057 against 1.055 ms on one channel at D = 208 -- tile boundaries are not what holds this kernel back (DESIGN.md
 // section 6).  Build-time knob for A/B measurements only.
+// Loader waves (two extra waves that feed the ring and emit) up to this many k steps.  13 fits the registers (157) and is
+// 4 % faster on the five-target launch (8.9 against 9.1-9.6 ms) but loosens the lock-step of a range's lanes: the launch's
+// L2 misses rise from 1.003x the capture to 1.1-1.4x, varying from launch to launch (FETCH_SIZE: 5.4-7.0 GB against a
+// steady 4.81 GB).  The shared-ingest design is about that number, so the multiplying waves keep issuing at 9..16 k steps.
 #ifndef IQA_RING_LOADERS_MAX_KS
-#define IQA_RING_LOADERS_MAX_KS 13
+#define IQA_RING_LOADERS_MAX_KS 8
 #endif
 // A/B knobs for the waves' interplay on a SIMD (diagnostic builds): IQA_RING_DEFER 0 = parity-1 waves scatter their tile
 // right behind it like parity 0; IQA_RING_PRIO 1 = parity-1 waves run at raised priority (s_setprio 1), 2 = parity-0 waves.

@@ -1,5 +1,10 @@
-"""Progress / cancel boundary types (the six-method sink contract of the reference's
-``progress.py:13-78,159-242``).  Pure host bookkeeping; the pipeline calls it between blocks."""
+"""Progress / cancel boundary of the pipeline.
+
+What a caller implements is the reference's sink contract (``progress.py:13-78``): a ``PhaseState`` record per phase and
+a sink with ``start / advance / status / close / set_cancel_callback / cancel``.  The reference's own sinks (tqdm bars,
+the Qt bridge) are UI and out of scope; here are the contract, a sink that ignores everything, and the small fan-out
+object the pipeline drives between device blocks -- pure host bookkeeping.
+"""
 from __future__ import annotations
 
 from collections.abc import Callable, Iterable
@@ -8,6 +13,8 @@ from dataclasses import dataclass
 
 @dataclass
 class PhaseState:
+    """One phase of a run as the sink sees it (field set of the reference's record)."""
+
     key: str
     label: str
     total: float
@@ -15,11 +22,12 @@ class PhaseState:
     completed: float = 0.0
 
     def remaining(self) -> float:
-        return max(self.total - self.completed, 0.0)
+        return self.total - self.completed if self.completed < self.total else 0.0
 
 
 class ProgressSink:
-    """Interface for receiving progress events."""
+    """Receiver of progress events.  A sink overrides what it needs; the three reporting methods and ``close`` /
+    ``cancel`` have no default behaviour on purpose (a sink that forgets one fails loudly, as in the reference)."""
 
     def start(self, phases: Iterable[PhaseState], *, overall_total: float) -> None:
         raise NotImplementedError
@@ -33,54 +41,54 @@ class ProgressSink:
     def close(self) -> None:
         raise NotImplementedError
 
-    def set_cancel_callback(self, callback: Callable[[], None]) -> None:
-        return
-
     def cancel(self) -> None:
         raise NotImplementedError
 
+    def set_cancel_callback(self, callback: Callable[[], None]) -> None:
+        """Optional: a sink with a cancel control keeps ``callback`` and calls it when the user asks to stop."""
+
 
 class NullProgressSink(ProgressSink):
+    """Swallows every event (what ``run(progress_sink=None)`` uses)."""
+
     def start(self, phases, *, overall_total):
-        return
+        pass
 
     def advance(self, phase, delta, *, overall_completed, overall_total):
-        return
+        pass
 
     def status(self, message):
-        return
+        pass
 
     def close(self):
-        return
+        pass
 
     def cancel(self):
-        return
+        pass
 
 
 class ProgressTracker:
-    """Fans pipeline events out to a sink and keeps per-phase totals."""
+    """The pipeline's side of the contract: phases by key, running totals, and the cancelled flag a sink may raise."""
 
     def __init__(self, sink: ProgressSink | None):
-        self.sink = sink or NullProgressSink()
+        self.sink = sink if sink is not None else NullProgressSink()
         self.phases: dict[str, PhaseState] = {}
         self.cancelled = False
-        self._total = 0.0
-        self._done = 0.0
+        self._done = self._total = 0.0
 
     def start(self, phases: Iterable[PhaseState]) -> None:
-        plist = list(phases)
-        self.phases = {p.key: p for p in plist}
-        self._total = float(sum(max(p.total, 0.0) for p in plist))
-        self._done = 0.0
-        self.sink.start(plist, overall_total=self._total)
+        listed = list(phases)
+        self.phases = {ph.key: ph for ph in listed}
+        self._done, self._total = 0.0, float(sum(ph.total for ph in listed if ph.total > 0))
+        self.sink.start(listed, overall_total=self._total)
 
     def advance(self, key: str, delta: float) -> None:
+        """``delta`` more units of phase ``key`` are done (unknown phases and non-positive deltas are ignored)."""
         phase = self.phases.get(key)
-        if phase is None or delta <= 0:
-            return
-        phase.completed += delta
-        self._done += delta
-        self.sink.advance(phase, delta, overall_completed=self._done, overall_total=self._total)
+        if phase is not None and delta > 0:
+            phase.completed += delta
+            self._done += delta
+            self.sink.advance(phase, delta, overall_completed=self._done, overall_total=self._total)
 
     def status(self, message: str) -> None:
         self.sink.status(message)
@@ -89,7 +97,7 @@ class ProgressTracker:
         self.cancelled = True
         try:
             self.sink.cancel()
-        except NotImplementedError:
+        except NotImplementedError:  # a sink without a cancel control
             pass
 
     def close(self) -> None:
