@@ -593,3 +593,50 @@ def test_precision_guard_routes_a_very_weak_nfm_channel_to_the_float32_kernel(A,
         err = rms(got - want.audio)
         print(f"precision guard: target {off:+.0f} Hz through {o.channelizer_kernel}: audio rms err {err:.2e}")
         assert err < 1e-4, (off, err)
+
+
+def test_demodulate_sharded_single_process_both_axes(A):
+    """batch.demodulate_sharded -- the function an N-GPU job calls on every rank (dist.run_sharded underneath; its
+    collectives are driven over gloo in tests/test_dist_gloo.py) -- without a process group, i.e. as rank 0 of 1: the
+    channel axis (one capture, the targets as one bank) and the capture axis (two captures, every target each) must give
+    each unit's 48 kHz PCM16 as the oracle's chain + resampler does."""
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd.batch import demodulate_sharded
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+
+    fs, secs = 2.5e6, 0.8
+    targets = [dict(freq_offset=25e3, demod_mode="nfm"), dict(freq_offset=-150e3, demod_mode="am", bandwidth=10_000.0)]
+    caps = [synthetic_multi_iq_s16(fs, secs, [(25e3, 0.3, "nfm"), (-150e3, 0.3, "am")], seed=s) for s in (42, 43)]
+    n = caps[0].shape[0]
+
+    def ref48(cap, spec):
+        w = O.run_chain(cap, sample_rate=fs, freq_offset=spec["freq_offset"], bandwidth=spec.get("bandwidth", 12_500.0),
+                        demod_mode=spec["demod_mode"], keep_decimated=False)
+        return O.float_to_pcm16(O.resample_48k(w.audio, w.fs_channel)), w.audio_peak
+
+    got, peak = demodulate_sharded(targets, sample_rate=fs, n_frames=n, axis="channels", capture=D.to_device(caps[0].reshape(-1), "int16"))
+    assert sorted(got) == [0, 1]
+    peaks = []
+    for i, spec in enumerate(targets):
+        want, pk = ref48(caps[0], spec)
+        peaks.append(pk)
+        assert got[i].dtype == np.int16 and got[i].size == want.size
+        assert np.max(np.abs(got[i].astype(np.int32) - want.astype(np.int32))) <= 1
+    assert abs(peak - max(peaks)) < 1e-4
+    loads = []
+
+    def loader(k):
+        def load():
+            loads.append(k)  # a capture is loaded by the rank that owns it, once
+            return D.to_device(caps[k].reshape(-1), "int16")
+        return load
+
+    got, _ = demodulate_sharded(targets, sample_rate=fs, n_frames=n, axis="captures", captures=[loader(0), loader(1)])
+    assert sorted(got) == [0, 1] and loads == [0, 1]
+    for k in (0, 1):
+        assert got[k].shape[0] == len(targets)
+        for i, spec in enumerate(targets):
+            want, _ = ref48(caps[k], spec)
+            assert np.max(np.abs(got[k][i].astype(np.int32) - want.astype(np.int32))) <= 1
+    with pytest.raises(ValueError):
+        demodulate_sharded(targets, sample_rate=fs, n_frames=n, axis="files")
