@@ -312,6 +312,13 @@ int iqa_float_to_pcm16(const void *y_dev, int64_t n, void *pcm_dev, void *stream
  * (<= 0: 8), so that the copy can run beside a kernel that occupies every CU.  Both pointers 16-byte aligned. */
 int iqa_trickle_copy(const void *src_dev, void *dst_mapped, int64_t nbytes, int32_t workgroups, void *stream);
 
+/* float32 capture -> int16 copy when, and only when, every value is k / 32768 with k an integer in [-32768, 32767]
+ * (what SDR software writes for int16 / 12-bit / int8 ADC samples): s16_out[i] = x[i] * 32768, and *flag_dev (int32,
+ * zeroed by the caller) is OR-ed with 1 if any value is NOT of that form -- the copy is then not the capture.  Lets
+ * cf32 captures that are integer captures in disguise take the matrix-core channelizers (ingest: IQReader._extract_iq,
+ * processing.py:268-279, with ffmpeg's f32le -> float being the identity).  f32_dev 16-byte aligned. */
+int iqa_f32_to_s16_exact(const void *f32_dev, int64_t n_values, void *s16_out_dev, void *flag_dev, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Spectrum / waterfall                                   *
  * ------------------------------------------------------------------------- */

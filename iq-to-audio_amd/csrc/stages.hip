@@ -6,6 +6,8 @@
 // stage API is complete and so that the fused path can be checked stage by stage.
 #include "common.h"
 
+#include <algorithm>
+
 #include <cstring>
 
 namespace iqa {
@@ -109,4 +111,52 @@ extern "C" int iqa_oscillator_mix(int32_t fmt, int32_t iq_order, const void *in_
             break;
     }
     return check_launch("k_oscillator_mix");
+}
+
+// ---- float32 captures that are integer captures in disguise ---------------------------------------------------------
+// SDR software stores int16 / 12-bit / int8 ADC samples as float32 scaled by a power of two (k / 32768, k / 2048,
+// k / 128): such a cf32 capture IS an int16 capture and can take the matrix-core channelizers, which need integer data.
+// One pass: every value is multiplied by 32768 (exact in float32), written as int16, and the flag word is set if any
+// value was NOT an integer in [-32768, 32767] -- then the int16 copy is not the capture and the caller stays on the
+// float32 kernel.  The conversion the reference sees is ffmpeg's f32le -> float (no scaling), so nothing changes for it.
+namespace iqa {
+__global__ __launch_bounds__(256) void k_f32_to_s16_exact(const float4 *in, long long n4, const float *in_tail, int n_tail,
+                                                          short *out, int *flag)
+{
+    bool bad = false;
+    auto conv = [&](float x) -> short {
+        const float sc = x * 32768.0f;  // a power of two: exact
+        const float r = rintf(sc);
+        bad |= !(r == sc) || r > 32767.0f || r < -32768.0f;  // (NaN fails r == sc)
+        return static_cast<short>(fminf(fmaxf(r, -32768.0f), 32767.0f));
+    };
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = in[i];
+        short4 o;
+        o.x = conv(v.x);
+        o.y = conv(v.y);
+        o.z = conv(v.z);
+        o.w = conv(v.w);
+        reinterpret_cast<short4 *>(out)[i] = o;
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < n_tail) out[4 * n4 + threadIdx.x] = conv(in_tail[threadIdx.x]);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace iqa
+
+extern "C" int iqa_f32_to_s16_exact(const void *f32_dev, int64_t n_values, void *s16_out_dev, void *flag_dev, void *stream)
+{
+    if (n_values < 0) return fail_inval("negative length");
+    if (n_values == 0) return IQA_OK;
+    if (!f32_dev || !s16_out_dev || !flag_dev) return fail_inval("NULL device pointer");
+    if ((reinterpret_cast<uintptr_t>(f32_dev) & 15) || (reinterpret_cast<uintptr_t>(s16_out_dev) & 7))
+        return fail_inval("input must be 16-byte aligned, output 8-byte aligned");
+    const long long n4 = n_values / 4;
+    const int n_tail = static_cast<int>(n_values - 4 * n4);
+    const float *tail = static_cast<const float *>(f32_dev) + 4 * n4;
+    const unsigned blocks = static_cast<unsigned>(std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 256 * 16));
+    hipLaunchKernelGGL(iqa::k_f32_to_s16_exact, dim3(blocks), dim3(256), 0, iqa::as_stream(stream), static_cast<const float4 *>(f32_dev), n4,
+                       tail, n_tail, static_cast<short *>(s16_out_dev), static_cast<int *>(flag_dev));
+    return iqa::check_launch("k_f32_to_s16_exact");
 }

@@ -1023,6 +1023,7 @@ class ProcessingPipeline:
         self.audio_fs_channel = None  # device float32 tensor of the clipped channel-rate audio (kept for tests)
         self.keep_channel_audio = False
         self.channelizer_kernel = None  # name of the channelizer kernel that produced the last block of the run
+        self.f32_integer_path = True  # float32 captures whose values are all k / 32768 run as int16 on the matrix cores
 
     def cancel(self) -> None:
         self._cancelled = True
@@ -1082,9 +1083,9 @@ class _Target:
         self.peak = 0.0
         self.output_path = cfg.output_path if cfg.output_path else owner._default_output_path(info)
 
-    def _channelizer(self, sign: int, exact: bool = False) -> Channelizer:
+    def _channelizer(self, sign: int, exact: bool = False, fmt: str | None = None) -> Channelizer:
         return Channelizer(self.taps, sample_rate=self.sample_rate, freq_offset=self.freq_offset, mix_sign=sign,
-                           decimation=self.decimation, fmt=self.info.fmt, iq_order=self.cfg.iq_order, exact=exact)
+                           decimation=self.decimation, fmt=fmt or self.info.fmt, iq_order=self.cfg.iq_order, exact=exact)
 
     #: Precision guard.  The fixed-point channelizers' error is a fraction of the WIDEBAND level whatever the channel
     #: holds (~ err_norm x wideband RMS, 1..5 x that on tonal captures), and the FM discriminator divides by the channel's
@@ -1153,7 +1154,7 @@ class _Target:
 
     def finish(self) -> None:
         cfg, info = self.cfg, self.info
-        self.owner.channelizer_kernel = self.chan._kernel.last_kernel
+        self.owner.channelizer_kernel = getattr(self, "chan16_kernel", None) or self.chan._kernel.last_kernel
         self.output_path.parent.mkdir(parents=True, exist_ok=True)
         if cfg.dump_iq_path:
             Path(cfg.dump_iq_path).write_bytes(self.z_all[: self.pos_dec].cpu().numpy().astype(np.complex64).tobytes())
@@ -1319,6 +1320,16 @@ class MultiChannelPipeline:
                 members = [t for t in targets if (t.decimation, t.chan._kernel.exact) == key]  # (float32-guarded channels run alone)
                 banks.append((ChannelBank([t.chan for t in members]), members))
             self.banks = [b for b, _ in banks]
+            # float32 captures that are integer captures in disguise (every value k / 32768: what SDR software writes for
+            # int16 / 12-bit / int8 ADC samples): each block is re-packed to int16 on the device, checked value by value
+            # (iqa_f32_to_s16_exact), and takes the matrix-core channelizers; the first block that is NOT of that form
+            # switches the rest of the run to the float32 kernel (whose state has been carried along all the time).
+            banks16 = None
+            if info.fmt == "f32" and self.owners[0].f32_integer_path:
+                banks16 = [(ChannelBank([t._channelizer(t.mix_sign, exact=t.chan._kernel.exact, fmt="s16") for t in members]), members)
+                           for _, members in banks]
+                flag16 = D.zeros(1, "int32")
+            self.integer_blocks = 0  # blocks of a float32 capture that ran as int16
             done = 0
             while done < total:
                 _check_cancel(f"block at frame {done}")
@@ -1329,11 +1340,30 @@ class MultiChannelPipeline:
                 n = hi - done
                 tracker.advance("ingest", float(n))
                 tracker.status(f"channel @ {done}")
-                for bank, members in banks:  # one pass over the block per decimation, all its channels at once
+                raw16 = None
+                if banks16 is not None:
+                    raw16 = D.empty(2 * n, "int16")
+                    N.call("iqa_f32_to_s16_exact", N.ptr(raw), c_int64(2 * n), N.ptr(raw16), N.ptr(flag16), N.stream_ptr())
+                    if int(flag16.item()):  # (a host read per 64 Mi-frame block)
+                        LOG.info("float32 capture is not an integer capture from frame %d on: float32 channelizer.", done)
+                        banks16 = raw16 = None
+                for bi, (bank, members) in enumerate(banks):  # one pass over the block per decimation, all its channels at once
                     for t in members:
                         t.before_block(done, n, chunk)
-                    for t, z in zip(members, bank.process(raw)):
+                    if raw16 is not None:
+                        zs = banks16[bi][0].process(raw16)
+                        x32, _ = _as_frames(raw, "f32")
+                        for c in bank.chans:  # the float32 channelizers' state moves along (history, position)
+                            c._advance(x32, n)
+                    else:
+                        zs = bank.process(raw)
+                    for t, z in zip(members, zs):
                         t.after_block(z, tracker)
+                if raw16 is not None:
+                    self.integer_blocks += 1
+                for bi, (_, members) in enumerate(banks):
+                    for ti, t in enumerate(members):  # (for finish(): which kernel produced this target's last block)
+                        t.chan16_kernel = banks16[bi][0].chans[ti]._kernel.last_kernel if raw16 is not None else None
                 _check_cancel("encode")
                 done = hi
 

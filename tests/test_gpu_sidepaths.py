@@ -184,3 +184,49 @@ def test_cli_preview_and_pass_through_naming(A, tmp_path):
     assert cli.main(["--in", str(src), "--ft", str(FC + F_OFF), "--demod", "none", "--out", str(tmp_path / "s.wav")]) == 0
     info = iqio.probe_capture(tmp_path / "s.wav")
     assert info.n_frames == -(-raw.size // 2 // 26) and info.codec == "pcm_s16le"
+
+
+def test_float32_capture_that_is_an_integer_capture_takes_the_matrix_cores(A, tmp_path):
+    """A cf32 capture whose values are all k / 32768 (what SDR software writes for int16 ADC samples) is re-packed to
+    int16 block by block on the device (iqa_f32_to_s16_exact checks every value) and runs on the matrix-core
+    channelizers: its audio is EXACTLY the audio of the same capture stored as cs16.  A capture with a single value that
+    is not of that form in its last block switches to the float32 kernel there -- state carried along -- and still meets
+    the oracle."""
+    import torch
+
+    fs, secs = 2.5e6, 1.6
+    s16 = O.synth_capture_s16(FS, secs, F_OFF).reshape(-1)
+    f32 = s16.astype(np.float32) / np.float32(32768.0)
+    outs = {}
+    for name, data, suffix in (("s16", s16, ".cs16"), ("f32", f32, ".cf32")):
+        path = tmp_path / f"cap_{int(FC)}Hz{suffix}"
+        path.write_bytes(data.tobytes())
+        pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=path, target_freq=FC + F_OFF, input_sample_rate=fs,
+                                                       output_path=tmp_path / f"{name}.wav"))
+        pipe.block_frames_target = 1_048_576  # four device blocks
+        pipe.keep_channel_audio = True
+        pipe.run()
+        outs[name] = (pipe.audio_fs_channel.clone(), pipe.channelizer_kernel, pipe._multi.integer_blocks)
+    assert outs["f32"][1] == outs["s16"][1] == "k_channelize_mfma_s16_ring"
+    assert (outs["s16"][2], outs["f32"][2]) == (0, 4)
+    assert torch.equal(outs["f32"][0], outs["s16"][0])
+    # one value off the 2^-15 grid in the last block
+    bent = f32.copy()
+    bent[2 * 3_500_000 + 1] += np.float32(1e-6)
+    path = tmp_path / f"bent_{int(FC)}Hz.cf32"
+    path.write_bytes(bent.tobytes())
+    pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=path, target_freq=FC + F_OFF, input_sample_rate=fs, output_path=tmp_path / "b.wav"))
+    pipe.block_frames_target = 1_048_576
+    pipe.keep_channel_audio = True
+    pipe.run()
+    assert pipe._multi.integer_blocks == 3 and pipe.channelizer_kernel == "k_channelize_v1"
+    want = O.run_chain(bent, sample_rate=fs, freq_offset=F_OFF, fmt="f32", keep_decimated=False)
+    got = pipe.audio_fs_channel.cpu().numpy()
+    assert got.size == want.audio.size
+    assert float(np.sqrt(np.mean((got - want.audio) ** 2))) < 2e-5
+    # and the switch itself
+    pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=tmp_path / f"cap_{int(FC)}Hz.cf32", target_freq=FC + F_OFF,
+                                                   input_sample_rate=fs, output_path=tmp_path / "off.wav"))
+    pipe.f32_integer_path = False
+    pipe.run()
+    assert pipe._multi.integer_blocks == 0 and pipe.channelizer_kernel == "k_channelize_v1"
