@@ -196,7 +196,7 @@ def test_float32_capture_that_is_an_integer_capture_takes_the_matrix_cores(A, tm
     the oracle."""
     import torch
 
-    fs, secs = 2.5e6, 1.6
+    fs, secs = 2.5e6, 4 * 1_048_576 / 2.5e6  # four device blocks of one reference chunk each
     s16 = O.synth_capture_s16(FS, secs, F_OFF).reshape(-1)
     f32 = s16.astype(np.float32) / np.float32(32768.0)
     outs = {}
