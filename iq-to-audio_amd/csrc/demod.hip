@@ -15,6 +15,7 @@
 // associatively, so they run here as a 3-launch block scan (reduce -> carry -> apply)
 // in float64.  The AGC's "gain restarts at 1.0 on every process() call" becomes a
 // segmented scan: at a restart index the element's map is the constant a+b.
+#include <cstdlib>
 #include "scan_common.h"
 
 namespace iqa {
@@ -360,58 +361,193 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 // output residues (rows p, p+inc, p+2inc, ... with inc = down mod up), one per group of four lanes, which keeps
 // that row's taps in registers (lane `sub` holds taps sub, sub+4, ...).  Per step g the wave produces the 16
 // consecutive outputs J0+16w .. +15 (+ g*up): their input windows overlap almost entirely (16 outputs x 67 taps
-// touch ~100 inputs), so the wave stages that stretch of the input ONCE in its own 1 KB of LDS (two coalesced loads,
-// prefetched a step ahead, zeros outside [0, n_in)) and every lane picks its taps' samples from there -- per-lane
-// global loads (17 per lane and step) moved 268 B per output through the L1 and were what the kernel waited for.
-// The cross-lane reduction is two quad steps per output.
-// Sum over the four lanes of a quad, in every lane: two DPP quad permutes (register-to-register; __shfl_xor goes
-// through ds_bpermute and its LDS latency, twice in a row, once per output).
+// touch ~100 inputs), so the wave stages that stretch of the input ONCE in LDS and every lane picks its taps' samples
+// from there.
+//
+// What the kernel waited for in its first form (46.5 us at config 2, two thirds of it idle) was the memory system's
+// LATENCY, twice per step: consecutive steps of a wave lie `down` inputs apart (192 KB at config 2), so every step's
+// window is a fresh L2/MALL access, and it was fetched only one step ahead; and the step's (branched) store made hipcc
+// wait for vmcnt(0) in front of the next step's window -- i.e. for the store's acknowledgement.  Now the windows of the
+// next RS_AHEAD steps are in flight at any time: LDS-DMA (buffer_load_dwordx4 ... lds, ONE instruction per window,
+// range-checked: positions outside [0, n_in) arrive as zeros) into a ring of RS_RING windows per wave, no registers, and
+// ONE counted wait per step that leaves the younger windows and the stores of the last two groups of steps outstanding.
+// For that count to be exact every group of steps issues the same number of stores: unconditional buffer stores whose
+// offset is out of range in lanes that have nothing to write, and the prologue pads with dropped stores; the number of
+// younger windows is wave-uniform (it shrinks over a wave's last RS_AHEAD steps) and selects the wait.
+//
+// Steps go in groups of RS_GROUP = 4: the four sums of a group stay in registers (per lane: its taps' share of each) and
+// are reduced ACROSS the quad in one transposing pass -- lane k of the quad ends up with the whole sum of step k -- so
+// the rounding to float32, the PCM16 conversion and the store run once per group in all lanes instead of once per step
+// in one lane of four, and the four steps' chains of float64 FMAs are independent of each other.  The order of the
+// additions per output is the one of the first form: ((lane 0 + lane 2) + (lane 1 + lane 3)) of ((a0+a1)+(a2+a3)).
+
+// value of lane ^ 2 (CTRL 0x4E) / lane ^ 1 (0xB1) within each quad: DPP quad permutes, register to register
+// (__shfl_xor goes through ds_bpermute and its LDS latency)
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true),
+                            __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the four lanes of a quad, in every lane.
 __device__ __forceinline__ double quad_sum(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));  // lanes ^ 2
-    lo = __double2loint(v);
-    hi = __double2hiint(v);
-    v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));  // lanes ^ 1
+    v += quad_swap<0x4E>(v);
+    v += quad_swap<0xB1>(v);
     return v;
 }
 
-constexpr int RS_WAVES = 4;
-constexpr int RS_LANES = 4;     // lanes per output
-constexpr int RS_WINDOW = 256;  // floats of LDS per wave: 4*NI taps + the spread of the 16 outputs' positions
-constexpr int RS_SPREAD = 60;   // largest spread of input positions inside a wave that the staged window covers
-
-template <int NI>  // taps per lane = ceil(row_len / 4)
-__global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, long long n_in, const double *table, int up,
-                                                               int down, int T, long long j0, long long n_out, float *y,
-                                                               short *pcm, int split)
+// pcm16_of on float32 alone: y * 32768 is exact in float32 (a power of two), so rounding it there is rounding the
+// float64 product; +-inf and NaN end where pcm16_of sends them.
+__device__ __forceinline__ short pcm16_of_f32(float y)
 {
-    static_assert(4 * NI + RS_SPREAD + 4 <= RS_WINDOW, "window too small for this row length");
-    constexpr int CHUNKS = (4 * NI + RS_SPREAD + 63) / 64;  // staging loads per lane and step
-    __shared__ float s_x[RS_WAVES][RS_WINDOW];
-    const int lane = threadIdx.x & 63, sub = lane & (RS_LANES - 1), slot = lane >> 2, wv = threadIdx.x >> 6;
-    const long long wid = static_cast<long long>(blockIdx.x) * RS_WAVES + wv;
-    const long long w = wid / split;  // group of 16 residues of (j0 + jj) mod up handled by this wave
-    const int part = static_cast<int>(wid - w * split);
-    if (w * 16 >= up) return;
+    const float v = rintf(y * 32768.0f);
+    return static_cast<short>(static_cast<int>(fminf(fmaxf(v, -32768.0f), 32767.0f)));
+}
+
+#ifndef IQA_RS_TARGET_WAVES
+#define IQA_RS_TARGET_WAVES 8192
+#endif
+#ifndef IQA_RS_ABLATE
+#define IQA_RS_ABLATE 0  // timing experiments only: 1 no stores, 2 no window DMAs, 4 no window reads / FMAs, 8 no table loads
+#endif
+constexpr int RS_WAVES = 4;
+constexpr int RS_LANES = 4;    // lanes per output
+constexpr int RS_GROUP = 4;    // steps whose sums are reduced and stored together (= RS_LANES: one per lane of the quad)
+constexpr int RS_AHEAD = 8;    // windows in flight behind the one being read: two groups of steps
+constexpr int RS_RING = RS_AHEAD + 2;  // + the one being read + the one read a step ago (its reads may still be in the LDS queue)
+constexpr unsigned int RS_NOWHERE = 0x80000000u;  // buffer offset beyond every descriptor used here: the access is dropped
+static_assert(RS_AHEAD == 2 * RS_GROUP && RS_GROUP == RS_LANES, "the counted wait assumes exactly two groups of stores per RS_AHEAD steps");
+
+typedef __attribute__((address_space(3))) void rs_lds_t;
+
+template <int NI>
+struct RsGeo {
+    // largest spread of input positions inside a wave that the staged window covers: the 16 outputs of a step lie
+    // 15 down/up inputs apart and a row has ~32 down/up taps, i.e. ~1.9 NI -- waves with more (a ratio that outgrows the
+    // one-instruction window, or residues that wrap around `up`) read their samples straight from memory
+    static constexpr int SPREAD = (2 * NI + 2 < 253 - 4 * NI) ? 2 * NI + 2 : 253 - 4 * NI;
+    // a window starts at a multiple of 4 samples (16-byte DMA lanes that never straddle x[0]): up to 3 samples of slack
+    static constexpr int CHUNKS = (4 * NI + SPREAD + 3 + 63) / 64;  // 64-float quarters of the one DMA
+    static constexpr int WINDOW = 64 * CHUNKS;                      // floats
+    static_assert(SPREAD >= 16 && CHUNKS <= 4, "a window is at most 64 lanes x 16 bytes");
+};
+
+struct RsArgs {
+    const float *x;
+    long long n_in;
+    const double *table;
+    int up, down, T, split;
+    long long n_out;
+    float *y;
+    short *pcm;
+    // host-side quotients (the kernel would spend a third of its instructions on 64-bit divisions otherwise)
+    long long g_all;   // ceil(n_out / up): steps any residue can need
+    long long g_per;   // ceil(g_all / split): steps per wave
+    int j0_mod_up;     // j0 mod up
+    long long j0_q;    // floor(j0 * down / up)
+    long long j0_r;    // (j0 * down) mod up
+};
+
+// floor(num / den) and the remainder for 0 <= num < 2^52, 0 < den < 2^31: one float64 division and a correction
+__device__ __forceinline__ long long rs_divmod(long long num, int den, int &rem)
+{
+    long long q = static_cast<long long>(static_cast<double>(num) / static_cast<double>(den));
+    long long r = num - q * den;
+    if (r < 0) { --q; r += den; }
+    else if (r >= den) { ++q; r -= den; }
+    rem = static_cast<int>(r);
+    return q;
+}
+
+// The few waves whose 16 residues straddle the wrap of (j0 + jj) mod up (their input positions lie far apart) and the
+// one with residues >= up: per-lane loads, no staging.  Same sums in the same order as the staged loop.
+template <int NI>
+__device__ __forceinline__ void resample_unstaged(const float *x, long long n_in, const double (&h)[NI], long long q0, int down, int T,
+                                                   int sub, long long jj0, int up, long long g_lo, long long g_hi, long long n_out,
+                                                   float *y, short *pcm)
+{
+    for (long long g = g_lo; g < g_hi; ++g) {
+        const long long jj = jj0 + g * up;
+        const long long top = q0 + g * down + T - sub;  // input index of this lane's first tap; tap i reads top - 4 i
+        float xv[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const long long nidx = top - RS_LANES * i;
+            const float v = x[min(max(nidx, 0LL), max(n_in - 1, 0LL))];
+            xv[i] = (nidx >= 0 && nidx < n_in) ? v : 0.f;
+        }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const double xd = static_cast<double>(xv[i]);
+            if ((i & 3) == 0) a0 = fma(h[i], xd, a0);
+            else if ((i & 3) == 1) a1 = fma(h[i], xd, a1);
+            else if ((i & 3) == 2) a2 = fma(h[i], xd, a2);
+            else a3 = fma(h[i], xd, a3);
+        }
+        const double acc = quad_sum((a0 + a1) + (a2 + a3));
+        if (jj < n_out && sub == 0) {
+            const float v = static_cast<float>(acc);
+            if (y != nullptr) y[jj] = v;
+            if (pcm != nullptr) pcm[jj] = pcm16_of_f32(v);
+        }
+    }
+}
+
+// One window = 64 CH consecutive floats in ONE 16-byte-per-lane DMA of the first 16 CH lanes (lane l: bytes
+// [voff, voff + 16) -> dst + 16 l); the texture addresser's cost is per lane and instruction, not per byte.
+template <int CH>
+__device__ __forceinline__ void rs_dma(__amdgpu_buffer_rsrc_t src, rs_lds_t *dst, int voff, int lane)
+{
+    static_assert(CH >= 1 && CH <= 4, "a window is at most 64 lanes x 16 bytes");
+    if (CH == 4 || lane < 16 * CH) __builtin_amdgcn_raw_ptr_buffer_load_lds(src, dst, 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ long long rs_uniform64(long long v)  // a value every lane holds, moved to scalar registers
+{
+    const int lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+    return (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo);
+}
+
+template <int NI, bool WANT_Y, bool WANT_PCM>  // NI: taps per lane = ceil(row_len / 4)
+__global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(RsArgs a)
+{
+    using G = RsGeo<NI>;
+    constexpr int CH = G::CHUNKS, WIN = G::WINDOW, NS = (WANT_Y ? 1 : 0) + (WANT_PCM ? 1 : 0);
+    // memory operations a wave issues behind a window's DMAs before it reads that window: the DMAs of the RS_AHEAD
+    // younger windows and the stores of the two groups that ended since
+    static_assert(RS_AHEAD + 2 * NS <= 63, "vmcnt holds six bits");
+    static_assert(4 * NI + G::SPREAD + 3 <= WIN, "window too small for this row length");
+    // (ONE LDS object on purpose: with two, hipcc tags their accesses with alias scopes and then drains vmcnt to 0 in
+    // front of every read of the ring -- it knows the DMAs write there, not which of them)
+    __shared__ float s_x[RS_WAVES][RS_RING][WIN];
+    const int up = a.up, down = a.down, T = a.T;
+    const int lane = threadIdx.x & 63, sub = lane & (RS_LANES - 1), slot = lane >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const unsigned int wid = blockIdx.x * RS_WAVES + wv;
+    const unsigned int w = wid / static_cast<unsigned int>(a.split);  // group of 16 residues of (j0 + jj) mod up handled by this wave
+    const int part = static_cast<int>(wid - w * a.split);
+    if (static_cast<long long>(w) * 16 >= up) return;
     const int row_len = 2 * T + 1;
-    const long long g_all = (n_out + up - 1) / up;  // steps any residue can need
-    const long long g_per = (g_all + split - 1) / split;
-    const long long g_lo = part * g_per, g_hi = min(g_all, g_lo + g_per);
+    const long long g_lo = part * a.g_per, g_hi = min(a.g_all, g_lo + a.g_per);
     if (g_lo >= g_hi) return;
     // this quad's residue: first output jj0, its input position q0 and its row
-    const long long res = w * 16 + slot;
+    const int res = static_cast<int>(w) * 16 + slot;
     const bool ok = res < up;
-    const long long jj0 = ok ? ((res - (j0 % up) + up) % up) : n_out;  // >= n_out: never live
-    const long long c0 = (j0 + (ok ? jj0 : 0)) * down;
-    const long long q0 = c0 / up;
-    const int p = static_cast<int>(c0 - q0 * up);
-    const double *row = table + static_cast<long long>(p) * row_len;
+    int jj0 = res - a.j0_mod_up;  // (res - j0 mod up) mod up
+    if (jj0 < 0) jj0 += up;
+    if (!ok) jj0 = 0;
+    // (j0 + jj0) * down = (j0_q * up + j0_r) + jj0 * down
+    int p;
+    const long long q0 = a.j0_q + rs_divmod(a.j0_r + static_cast<long long>(jj0) * down, up, p);
+    const double *row = a.table + static_cast<long long>(p) * row_len;
     // all loads unconditional (clamped index, masked afterwards): a branch around a load makes hipcc wait for
     // every load separately
     double h[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) h[i] = row[min(sub + RS_LANES * i, row_len - 1)];
+    for (int i = 0; i < NI; ++i) h[i] = (IQA_RS_ABLATE & 8) ? 1e-3 * (p + i) : row[min(sub + RS_LANES * i, row_len - 1)];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
         if (sub + RS_LANES * i >= row_len) h[i] = 0.0;
@@ -423,69 +559,108 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(const float *x, lo
         qmin = min(qmin, __shfl_xor(qmin, m, kWave));
         qmax = max(qmax, __shfl_xor(qmax, m, kWave));
     }
-    const bool staged = (qmax - qmin) <= RS_SPREAD;  // wave-uniform; false only where the residues wrap around `up`
-    float *win = s_x[wv];
-    const int my = ok ? static_cast<int>(q0 - qmin) + 4 * NI - 1 - sub : 4 * NI - 1 - sub;
-    const long long w_first = qmin + T - (4 * NI - 1);  // + g*down
-    // staging loads go through a buffer descriptor over x[0, n_in): positions outside it (the stream's edges) come
-    // back as zeros from the range check -- no clamps, no branches around the loads (hipcc waits for a branched load
-    // on the spot, which would undo the prefetch below)
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, static_cast<int>(n_in * 4), 0x00020000);
-    float nxt[CHUNKS];
-    if (staged) {
-        const int k0 = static_cast<int>(w_first + g_lo * down) + lane;
-#pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
-            nxt[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (k0 + 64 * c) * 4, 0, 0));
+    qmin = rs_uniform64(qmin);
+    qmax = rs_uniform64(qmax);
+    if (qmax - qmin > G::SPREAD) {  // (wave-uniform) only where the residues wrap around `up`
+        resample_unstaged<NI>(a.x, a.n_in, h, q0, down, T, sub, ok ? jj0 : a.n_out, up, g_lo, g_hi, a.n_out, WANT_Y ? a.y : nullptr,
+                              WANT_PCM ? a.pcm : nullptr);
+        return;
     }
-    for (long long g = g_lo; g < g_hi; ++g) {
-        const long long jj = jj0 + g * up;
-        float xv[NI];
-        if (staged) {
+    float *ring = &s_x[wv][0][0];
+    // this lane's LAST tap's sample in a window; tap i's lies 4 (NI - 1 - i) above it
+    const int my_low = (ok ? static_cast<int>(q0 - qmin) : 0) + 3 - sub;
+    const long long w_first = qmin + T - (4 * NI - 1);  // + g*down: first position of step g's window
+
+    // input windows: one descriptor over x[0, n_in) -- positions outside it (the stream's edges) arrive as zeros --
+    // and the same with no records for the DMAs past this wave's last step
+    const int x_bytes = static_cast<int>(a.n_in * 4);
+    long long dma_pos = w_first + g_lo * down, rd_pos = dma_pos;  // first position of the next window to request / to read
+    const int steps = static_cast<int>(g_hi - g_lo);
+    unsigned int lane16 = 16u * lane;
+    int issued = 0;  // windows requested so far (wave-uniform)
+    auto issue = [&](int into) {
+        // past the wave's last step: no records -- dropped by the range check, still counted
+        const __amdgpu_buffer_rsrc_t src =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, issued < steps ? x_bytes : 0, 0x00020000);
+        // from the multiple of 4 samples at or below dma_pos (mod 2^32: a negative offset is out of range)
+        const unsigned int from = static_cast<unsigned int>((dma_pos & ~3LL) * 4);
+        if (!(IQA_RS_ABLATE & 2)) rs_dma<CH>(src, (rs_lds_t *)(ring + into * WIN), static_cast<int>(from + lane16), lane);
+        dma_pos += down;
+        ++issued;
+    };
+    // wait until the window of the current step has landed: behind its DMA the wave has issued the DMAs of the RS_AHEAD
+    // younger windows and the stores of two groups of steps
+    auto wait_window = [&](int) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((IQA_RS_ABLATE & 2) ? 0 : RS_AHEAD + 2 * NS) : "memory"); };
+    // outputs: descriptors over this wave's stretch [j_base, j_base + (g_hi - g_lo) up) of y / pcm, cut at n_out -- the
+    // range check is the `jj < n_out` test and the one for the steps past g_hi of the last group; lane k of a quad
+    // writes the group's step k; quads without a residue aim at RS_NOWHERE
+    const long long j_base = g_lo * up;
+    const long long j_cnt = min(a.n_out - j_base, (g_hi - g_lo) * up);
+    __amdgpu_buffer_rsrc_t y_dst, p_dst;
+    if constexpr (WANT_Y) y_dst = __builtin_amdgcn_make_buffer_rsrc(a.y + j_base, 0, static_cast<int>(j_cnt * 4), 0x00020000);
+    if constexpr (WANT_PCM) p_dst = __builtin_amdgcn_make_buffer_rsrc(a.pcm + j_base, 0, static_cast<int>(j_cnt * 2), 0x00020000);
+    const unsigned int first = static_cast<unsigned int>(jj0) + static_cast<unsigned int>(sub) * static_cast<unsigned int>(up);
+    unsigned int y_off = ok ? 4u * first : RS_NOWHERE, p_off = ok ? 2u * first : RS_NOWHERE;
+    const unsigned int y_inc = ok ? 4u * RS_GROUP * static_cast<unsigned int>(up) : 0u, p_inc = ok ? 2u * RS_GROUP * static_cast<unsigned int>(up) : 0u;
+    auto dropped_stores = [&]() {
+        if constexpr (WANT_Y) __builtin_amdgcn_raw_buffer_store_b32(0u, y_dst, static_cast<int>(RS_NOWHERE), 0, 0);
+        if constexpr (WANT_PCM) __builtin_amdgcn_raw_buffer_store_b16(static_cast<unsigned short>(0), p_dst, static_cast<int>(RS_NOWHERE), 0, 0);
+    };
+
+    // windows of the first RS_AHEAD steps, with (dropped) stores where two earlier groups would have ended
 #pragma unroll
-            for (int c = 0; c < CHUNKS; ++c)
-                if (lane + 64 * c < RS_WINDOW) win[lane + 64 * c] = nxt[c];
-            {  // next step's stretch: in flight while this one is multiplied (past the last step: harmless, in range or zero)
-                const int k0 = static_cast<int>(w_first + (g + 1) * down) + lane;
+    for (int r = 0; r < RS_AHEAD; ++r) {
+        issue(r);
+        if ((r + 1) % RS_GROUP == 0) dropped_stores();
+    }
+    int rd = 0, fill = RS_AHEAD;
+    for (int cur = 0; cur < steps; cur += RS_GROUP) {
+        double part_sum[RS_GROUP];  // this lane's taps' share of the group's four sums
 #pragma unroll
-                for (int c = 0; c < CHUNKS; ++c)
-                    nxt[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (k0 + 64 * c) * 4, 0, 0));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations complete in order
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < RS_GROUP; ++k) {
+            // refill the slot read TWO steps ago -- and only once that step's sum exists, i.e. its LDS reads have
+            // returned (steps 0 and 1 of a group: the previous group's stores, in front of this point, took its sums)
+            if (k >= 2) asm volatile("" : "+v"(lane16) : "v"(part_sum[k >= 2 ? k - 2 : 0]));
+            issue(fill);
+            wait_window(cur + k);
+            const float *low = ring + rd * WIN + static_cast<int>(rd_pos & 3) + my_low;
+            rd_pos += down;
+            float xv[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) xv[i] = win[my - RS_LANES * i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the next step's stores stay behind these reads
-        } else {
-            const long long top = q0 + g * down + T - sub;  // input index of this lane's first tap; tap i reads top - 4 i
+            for (int i = 0; i < NI; ++i) xv[i] = low[RS_LANES * (NI - 1 - i)];
+            // four independent chains per step
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const long long nidx = top - RS_LANES * i;
-                const float v = x[min(max(nidx, 0LL), max(n_in - 1, 0LL))];
-                xv[i] = (nidx >= 0 && nidx < n_in) ? v : 0.f;
+                const double xd = static_cast<double>(xv[i]);
+                if ((i & 3) == 0) a0 = fma(h[i], xd, a0);
+                else if ((i & 3) == 1) a1 = fma(h[i], xd, a1);
+                else if ((i & 3) == 2) a2 = fma(h[i], xd, a2);
+                else a3 = fma(h[i], xd, a3);
             }
+            part_sum[k] = (IQA_RS_ABLATE & 4) ? h[k] : (a0 + a1) + (a2 + a3);
+            asm volatile("" ::: "memory");  // this window's reads stay in front of the later DMAs
+            rd = rd + 1 == RS_RING ? 0 : rd + 1;
+            fill = fill + 1 == RS_RING ? 0 : fill + 1;
         }
-        // four independent chains: a wave has few neighbours to hide a 17-deep float64 FMA dependency behind
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const double xd = static_cast<double>(xv[i]);
-            if ((i & 3) == 0) a0 = fma(h[i], xd, a0);
-            else if ((i & 3) == 1) a1 = fma(h[i], xd, a1);
-            else if ((i & 3) == 2) a2 = fma(h[i], xd, a2);
-            else a3 = fma(h[i], xd, a3);
+        // transposing reduction over the quad: lanes 0, 1 collect steps 0, 1 and lanes 2, 3 steps 2, 3 (one exchange
+        // with lane ^ 2), then lane k keeps step k (one exchange with lane ^ 1)
+        const bool upper = (sub & 2) != 0, odd = (sub & 1) != 0;
+        const double r0 = (upper ? part_sum[2] : part_sum[0]) + quad_swap<0x4E>(upper ? part_sum[0] : part_sum[2]);
+        const double r1 = (upper ? part_sum[3] : part_sum[1]) + quad_swap<0x4E>(upper ? part_sum[1] : part_sum[3]);
+        const float v = static_cast<float>((odd ? r1 : r0) + quad_swap<0xB1>(odd ? r0 : r1));
+        if constexpr (WANT_Y) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), y_dst,
+                                                  static_cast<int>((IQA_RS_ABLATE & 1) && v != 1e30f ? RS_NOWHERE : y_off), 0, 0);
+            y_off += y_inc;
         }
-        double acc = (a0 + a1) + (a2 + a3);
-        acc = quad_sum(acc);
-        if (jj < n_out && sub == 0) {
-            const float v = static_cast<float>(acc);
-            if (y != nullptr) y[jj] = v;
-            if (pcm != nullptr) pcm[jj] = pcm16_of(v);  // the writer's PCM16 leg in the same pass
+        if constexpr (WANT_PCM) {  // the writer's PCM16 leg in the same pass
+            __builtin_amdgcn_raw_buffer_store_b16(static_cast<unsigned short>(pcm16_of_f32(v)), p_dst,
+                                                  static_cast<int>((IQA_RS_ABLATE & 1) && v != 1e30f ? RS_NOWHERE : p_off), 0, 0);
+            p_off += p_inc;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS the workgroup has given back
 }
 
 template <int OP>
@@ -656,21 +831,41 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     if (!table_dev || (!y_dev && !pcm16_dev) || (n_in > 0 && !x_dev)) return fail_inval("NULL device pointer");
     if (2 * T + 1 > 192) return fail_inval("resampler rows longer than 192 taps are not supported");
     if (n_in > (1LL << 30) - 4096) return fail_inval("resampler input longer than 2^30 samples: process it in blocks");
-    const int64_t g_total = (n_out + up - 1) / up;  // outputs per polyphase row
+    if (j0 > (1LL << 40) || static_cast<int64_t>(up) * down >= (1LL << 50)) return fail_inval("resampler position out of range");
+    RsArgs a;
+    a.x = static_cast<const float *>(x_dev);
+    a.n_in = n_in;
+    a.table = static_cast<const double *>(table_dev);
+    a.up = up, a.down = down, a.T = T;
+    a.n_out = n_out;
+    a.y = static_cast<float *>(y_dev);
+    a.pcm = static_cast<short *>(pcm16_dev);
+    a.g_all = (n_out + up - 1) / up;  // outputs per polyphase row
     // enough waves to fill the chip (>= ~8 per SIMD) while a wave still amortises its 4*NI tap loads over several steps
     const int64_t groups = (static_cast<int64_t>(up) + 15) / 16;
-    const int split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(g_total, (8192 + groups - 1) / groups)));
-    const dim3 grid = grid1d(groups * split, RS_WAVES), block(RS_WAVES * kWave);
+    a.split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(a.g_all, (IQA_RS_TARGET_WAVES + groups - 1) / groups)));
+    a.g_per = (a.g_all + a.split - 1) / a.split;
+    a.j0_mod_up = static_cast<int>(j0 % up);
+    a.j0_q = j0 * down / up;  // (j0 * down < 2^40 * 2^31: the sizes above keep it inside int64)
+    a.j0_r = j0 * down % up;
+    // a wave addresses its stretch of the output (its steps x up samples) with 32-bit buffer offsets
+    if ((a.g_per + RS_GROUP + 1) * static_cast<int64_t>(up) >= (1LL << 29))
+        return fail_inval("resampler output too long for one launch at this ratio: process it in blocks");
+    const dim3 grid = grid1d(groups * a.split, RS_WAVES), block(RS_WAVES * kWave);
     const int ni = (2 * T + 1 + 3) / 4;
-#define IQA_RS_LAUNCH(NI)                                                                                          \
-    hipLaunchKernelGGL((k_resample<NI>), grid, block, 0, as_stream(stream), static_cast<const float *>(x_dev),     \
-                       (long long)n_in, static_cast<const double *>(table_dev), (int)up, (int)down, (int)T,        \
-                       (long long)j0, (long long)n_out, static_cast<float *>(y_dev), static_cast<short *>(pcm16_dev), split)
+#define IQA_RS_LAUNCH_AS(NI, WY, WP) hipLaunchKernelGGL((k_resample<NI, WY, WP>), grid, block, 0, as_stream(stream), a)
+#define IQA_RS_LAUNCH(NI)                                         \
+    do {                                                          \
+        if (y_dev && pcm16_dev) IQA_RS_LAUNCH_AS(NI, true, true); \
+        else if (y_dev) IQA_RS_LAUNCH_AS(NI, true, false);        \
+        else IQA_RS_LAUNCH_AS(NI, false, true);                   \
+    } while (0)
     if (ni <= 17) IQA_RS_LAUNCH(17);
     else if (ni <= 24) IQA_RS_LAUNCH(24);
     else if (ni <= 32) IQA_RS_LAUNCH(32);
     else IQA_RS_LAUNCH(48);
 #undef IQA_RS_LAUNCH
+#undef IQA_RS_LAUNCH_AS
     return check_launch("k_resample");
 }
 

@@ -423,6 +423,13 @@ def test_resampler_matches_spec(A):
     N.call("iqa_resample", N.ptr(xd), c_int64(x.size), N.ptr(rs.table_dev), c_int32(rs.plan.up), c_int32(rs.plan.down),
            c_int32(rs.plan.half_taps), c_int64(j0), c_int64(cnt), N.ptr(part), N.ptr(None), N.stream_ptr())
     np.testing.assert_array_equal(part.cpu().numpy(), y.cpu().numpy()[j0 : j0 + cnt])
+    # stream lengths that are not multiples of 4 samples (the staging DMA moves 16 bytes per lane: its last lane
+    # straddles the end of the stream) and one shorter than a filter row
+    for m in (49_999, 49_998, 49_997, 77, 5):
+        ym, pm = rs.process(D.to_device(x[:m].copy(), "float32"), want="both")
+        wm = O.resample_48k(x[:m], fs_ch)
+        np.testing.assert_allclose(ym.cpu().numpy(), wm, rtol=0, atol=2e-7)
+        np.testing.assert_array_equal(pm.cpu().numpy(), O.float_to_pcm16(ym.cpu().numpy()))
     # C5's rate: gcd(48000, 95969) == 1
     rs5 = Resampler48k(50e6 / 521)
     y5 = rs5.process(D.to_device(x, "float32")).cpu().numpy()
