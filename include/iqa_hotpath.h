@@ -226,6 +226,12 @@ int iqa_decimate(const void *in_dev, int64_t n, int64_t first, int32_t D, void *
  * ref: choose_mix_sign, processing.py:650-658; baseband_power, processing.py:1105. */
 int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *power_dev, void *stream);
 
+/* The same for `parts` stretches of n_each samples that lie back to back in z_dev: power_dev[p] = mean(|z|^2) over
+ * z[p*n_each + skip : (p+1)*n_each].  One launch when a stretch has at most 65536 samples (then written, not
+ * accumulated: power_dev may be mapped pinned host memory) -- the two mixer-sign probes of choose_mix_sign
+ * (processing.py:623-663) side by side. */
+int iqa_mean_power_batch(const void *z_dev, int64_t n_each, int32_t parts, int64_t skip, void *power_dev, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Demodulators (channel rate)                                                 *
  * ------------------------------------------------------------------------- */

@@ -14,7 +14,7 @@
 // read twice and the audio written once: 20 B per channel sample instead of ~52.
 // SSB with AGC needs two dependent recurrences and therefore two scans (DC blocker to a float
 // scratch, then the segmented AGC scan with the sink).
-#include "scan_common.h"
+#include "../scan_common.h"
 
 namespace iqa {
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fused_carry(FusedArgs a)
 // `a.prev` / `a.st` point at the carry pass's snapshot; prev_out / st_out at the caller's state block (written by
 // the last block: the streaming state for the next call, OP != F_AGC)
 template <int OP, int SRC, int SINK>
-__global__ __launch_bounds__(SC_THREADS) void k_fused_apply(FusedArgs a, float2 *prev_out, double *st_out)
+__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_apply(FusedArgs a, float2 *prev_out, double *st_out)
 {
     __shared__ Aff s_w[SC_THREADS / kWave];
     __shared__ float s_pk[SC_THREADS / kWave];

@@ -247,10 +247,14 @@ __global__ __launch_bounds__(256) void k_mean_power(const float2 *z, long long n
 
 // Short inputs (the mixer-sign probes: a few thousand samples): one block, fixed summation order, the result is
 // WRITTEN -- no memset in front, no atomics.
+// (a grid of several blocks: block p reduces the p-th stretch of `stride` samples into out[p] -- the two mixer-sign probes
+// of a capture in one launch)
 __global__ __launch_bounds__(1024) void k_mean_power_small(const float2 *z, long long n, long long skip, double inv_count,
-                                                            double *out)
+                                                            double *out, long long stride)
 {
     __shared__ double s_w[16];
+    z += blockIdx.x * stride;
+    out += blockIdx.x;
     double acc = 0.0;
     for (long long i = skip + threadIdx.x; i < n; i += 1024) {
         const float2 v = z[i];
@@ -794,7 +798,7 @@ extern "C" int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *
     if (count > 0 && count <= 65536) {
         if (!z_dev) return fail_inval("NULL device pointer");
         hipLaunchKernelGGL(k_mean_power_small, dim3(1), dim3(1024), 0, s, static_cast<const float2 *>(z_dev), (long long)n,
-                           (long long)skip, 1.0 / static_cast<double>(count), static_cast<double *>(power_dev));
+                           (long long)skip, 1.0 / static_cast<double>(count), static_cast<double *>(power_dev), 0LL);
         return check_launch("k_mean_power_small");
     }
     if (hipMemsetAsync(power_dev, 0, sizeof(double), s) != hipSuccess) {
@@ -807,6 +811,27 @@ extern "C" int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *
     hipLaunchKernelGGL(k_mean_power, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float2 *>(z_dev),
                        (long long)n, (long long)skip, 1.0 / static_cast<double>(count), static_cast<double *>(power_dev));
     return check_launch("k_mean_power");
+}
+
+extern "C" int iqa_mean_power_batch(const void *z_dev, int64_t n_each, int32_t parts, int64_t skip, void *power_dev, void *stream)
+{
+    if (n_each < 0 || skip < 0 || skip > n_each || parts < 0) return fail_inval("bad range");
+    if (parts == 0) return IQA_OK;
+    if (!power_dev) return fail_inval("NULL device pointer");
+    const int64_t count = n_each - skip;
+    if (count > 0 && count <= 65536) {
+        if (!z_dev) return fail_inval("NULL device pointer");
+        hipLaunchKernelGGL(k_mean_power_small, dim3(static_cast<unsigned>(parts)), dim3(1024), 0, as_stream(stream),
+                           static_cast<const float2 *>(z_dev), (long long)n_each, (long long)skip, 1.0 / static_cast<double>(count),
+                           static_cast<double *>(power_dev), (long long)n_each);
+        return check_launch("k_mean_power_small");
+    }
+    for (int32_t p = 0; p < parts; ++p) {  // long stretches: one reduction each
+        const int rc = iqa_mean_power(z_dev ? static_cast<const float2 *>(z_dev) + static_cast<int64_t>(p) * n_each : nullptr, n_each, skip,
+                                      static_cast<double *>(power_dev) + p, stream);
+        if (rc != IQA_OK) return rc;
+    }
+    return IQA_OK;
 }
 
 extern "C" int iqa_writer_clip(const void *a_dev, int64_t n, void *peak_dev, const void *seg_starts_dev,
@@ -843,7 +868,9 @@ extern "C" int iqa_resample(const void *x_dev, int64_t n_in, const void *table_d
     a.g_all = (n_out + up - 1) / up;  // outputs per polyphase row
     // enough waves to fill the chip (>= ~8 per SIMD) while a wave still amortises its 4*NI tap loads over several steps
     const int64_t groups = (static_cast<int64_t>(up) + 15) / 16;
-    a.split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(a.g_all, (IQA_RS_TARGET_WAVES + groups - 1) / groups)));
+    // ... and never fewer than RS_GROUP steps per wave (short streams: a wave's prologue -- its 17 tap loads, the first
+    // windows -- costs as much as half a dozen steps)
+    a.split = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(a.g_all / RS_GROUP, (IQA_RS_TARGET_WAVES + groups - 1) / groups)));
     a.g_per = (a.g_all + a.split - 1) / a.split;
     a.j0_mod_up = static_cast<int>(j0 % up);
     a.j0_q = j0 * down / up;  // (j0 * down < 2^40 * 2^31: the sizes above keep it inside int64)

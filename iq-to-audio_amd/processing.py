@@ -583,6 +583,41 @@ class ChannelBank:
             c._advance(x, n, last_block)
         return zs
 
+    def run_interior_only(self, x_all, n_frames: int, m_first: int, n_out: int, outs: list) -> bool:
+        """Outputs [m_first, m_first + n_out) of a block that starts the capture, for every channel, in ONE launch and
+        matrix-core kernels only (no edges): what ``_ChannelKernel.run_interior_only`` does for one channel.  For
+        single-group, single-pass filters; False (nothing launched) otherwise."""
+        kernels = [c._kernel for c in self.chans]
+        if len(kernels) > self.MAX_LANES or n_out < 64 or not self._shared_shape():
+            return False
+        if any(k._interior(0, n_frames, m_first, n_out) != (m_first, m_first + n_out) for k in kernels):
+            return False
+        plans = [k._ensure_mfma() for k in kernels]
+        if any(len(mp.groups) != 1 or len(mp.passes) != 1 for mp in plans) or len({(mp.passes[0].k_first, mp.passes[0].k_count) for mp in plans}) != 1:
+            return False
+        ps0 = plans[0].passes[0]
+        ranges = 8 * max(1, (_ChannelKernel.launch_blocks // 8) // len(kernels))
+        rng = max(64, -(-(-(-n_out // ranges)) // 32) * 32)
+        table = (N.MfmaLane * len(kernels))()
+        for lane, k, mp, z in zip(table, kernels, plans, outs):
+            ps = mp.passes[0]
+            lane.afrag_dev = k.afrag_dev[0][ps.k_first * P.MFMA_KSTEP_BYTES :].data_ptr()
+            lane.z_out_dev = z.data_ptr()
+            lane.partial_in_dev = lane.partial_out_dev = None
+            lane.unit = mp.groups[0].unit / (256.0 if self.fmt == "u8" else 1.0)
+            lane.c_re, lane.c_im = ps.c_re, ps.c_im
+            lane.rot_step, lane.rot_base = k.params.rot_step, k.params.rot_base
+            lane.out_scale_re, lane.out_scale_im = k.params.out_scale_re, k.params.out_scale_im
+            lane.q_group, lane.finalize = 0, 1
+            lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
+            lane.raw_partials = 0
+            k.last_kernel = ("k_channelize_mfma_u8" if self.fmt == "u8" else "k_channelize_mfma_s16") + "_ring"
+        N.call("iqa_channelize_mfma_multi", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(ps0.k_first),
+               c_int32(ps0.k_count), c_int32(rng), table, c_int32(len(kernels)), N.ptr(x_all), c_int64(n_frames), c_int64(0),
+               c_int64(m_first), c_int64(n_out), N.stream_ptr())
+        self.last_launch = dict(lanes=len(kernels), launches=1, combines=0)
+        return True
+
     def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo):
         kernels = [c._kernel for c in self.chans]
         consumed = self.chans[0].consumed
@@ -712,12 +747,35 @@ class MixSignProbe:
         self._powers = D.empty(2, "float64")  # iqa_mean_power overwrites its slot
         self._host = _pinned_scalars(id(self))
         self._sign = None
-        for i, sign in enumerate((1, -1)):
-            self._probe_one(i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)
+        if not self._probe_pair(x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order):
+            for i, sign in enumerate((1, -1)):
+                self._probe_one(i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)
         self._done = None
         if record_done:
             self._done = D.torch_mod().cuda.Event()
             self._done.record()
+
+    def _probe_pair(self, x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order) -> bool:
+        """Both signs in two launches instead of four: the two channelizers as the two lanes of one matrix-core launch
+        over the snippet (shared ingest) and one reduction with a workgroup per sign, written into the pinned slot.
+        Only where ``_probe_one`` would take its interior-only path for both signs and a probe is short enough for the
+        single-workgroup reduction; False (nothing queued) otherwise."""
+        if fmt not in ("s16", "u8"):
+            return False
+        ntaps = len(taps)
+        n_z = -(-snippet_len // decim)
+        discard = min(ntaps, n_z // 4)
+        keep = n_z - discard
+        if keep <= 0 or keep > self.DIRECT_MAX:
+            return False
+        chans = [Channelizer(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=sign, decimation=decim, fmt=fmt,
+                             iq_order=iq_order) for sign in (1, -1)]
+        z_keep = D.empty(2 * keep, "complex64")
+        if not ChannelBank(chans).run_interior_only(x_all, n_in, discard, keep, [z_keep[:keep], z_keep[keep:]]):
+            return False
+        N.call("iqa_mean_power_batch", N.ptr(z_keep), c_int64(keep), c_int32(2), c_int64(0), N.ptr(self._host), N.stream_ptr())
+        self._valid = [True, True]
+        return True
 
     def _probe_one(self, i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order):
         """Queue the probe for one mixer sign on the current stream; its mean power ends up in ``_host[i]``."""

@@ -4,7 +4,11 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
+import os
 import iq_to_audio_amd as A
+from iq_to_audio_amd import _native as NATIVE
+if os.environ.get("IQA_LIB"):  # an experiment build of the library
+    NATIVE.LIB_PATH = Path(os.environ["IQA_LIB"]).resolve()
 from iq_to_audio_amd import _dev as D, dsp_plan as P
 from iq_to_audio_amd.processing import ChannelDemod, Resampler48k
 
