@@ -117,6 +117,47 @@ def test_choose_mix_sign_positive_offset(A):
     assert A.choose_mix_sign(warm[:0], fs, f, taps, 10) == 1
 
 
+def test_mix_sign_probes_share_a_launch(A):
+    """int16 / uint8 captures: both signs' probes are the two lanes of ONE matrix-core launch and one batched reduction
+    (MixSignProbe._probe_pair); the powers it reads are those of the one-sign-at-a-time path, and the decision is the
+    oracle's for a carrier on either side."""
+    from ctypes import c_int32, c_int64
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import _native as N
+    from iq_to_audio_amd.processing import MixSignProbe
+
+    fs, d, f_off = 2.5e6, 26, 25e3
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    for side in (1, -1):
+        raw = D.to_device(O.synth_capture_s16(fs, 0.4, side * f_off).reshape(-1), "int16")
+        pair = MixSignProbe(raw, fs, f_off, taps, d, fmt="s16")
+        assert pair._valid == [True, True]
+        sign = pair.result()
+        powers = []  # the same probes, one sign per launch
+        for s_ in (1, -1):
+            ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=s_, decimation=d, fmt="s16")
+            n_in = raw.numel() // 2
+            snippet = min(n_in, max(int(fs * 0.05), len(taps) * 4, 131_072))
+            n_z = -(-snippet // d)
+            discard = min(len(taps), n_z // 4)
+            z = D.empty(n_z - discard, "complex64")
+            assert ch._kernel.run_interior_only(raw, n_in, discard, n_z - discard, z)
+            zz = z.cpu().numpy()
+            powers.append(float(np.mean(np.abs(zz).astype(np.float32).astype(np.float64) ** 2)))
+        assert sign == side == (1 if powers[0] >= powers[1] else -1)
+        assert abs(pair.power - max(powers)) <= 1e-6 * max(powers)
+    # the batched reduction against numpy, short (one workgroup per part, written) and long (accumulated) parts
+    rng = np.random.default_rng(11)
+    for n_each, parts, skip in ((1000, 3, 7), (70_000, 2, 0)):
+        z = (rng.normal(size=n_each * parts) + 1j * rng.normal(size=n_each * parts)).astype(np.complex64)
+        out = D.empty(parts, "float64")
+        N.call("iqa_mean_power_batch", N.ptr(D.to_device(z, "complex64")), c_int64(n_each), c_int32(parts), c_int64(skip), N.ptr(out),
+               N.stream_ptr())
+        want = [np.mean(np.abs(z[p * n_each + skip : (p + 1) * n_each]).astype(np.float64) ** 2) for p in range(parts)]
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6)
+
+
 # ---- decoders ------------------------------------------------------------------------------------
 
 
