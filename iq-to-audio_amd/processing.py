@@ -995,6 +995,12 @@ class Resampler48k:
             raise ValueError(f"want must be 'f32', 'pcm16' or 'both', not {want!r}")
         n_in = int(audio_dev.numel())
         n_out = self.plan.n_out(n_in)
+        if self.plan.up == 1 and self.plan.down == 1:
+            # a channel rate of exactly 48 kHz: `-ar 48000` on a 48 kHz stream resamples nothing (the build-defined
+            # specification says so too: oracle resample_48k) -- the stream itself, and its PCM16
+            y = audio_dev.clone() if want != "pcm16" else None
+            pcm = self.to_pcm16(audio_dev) if want != "f32" else None
+            return y if want == "f32" else pcm if want == "pcm16" else (y, pcm)
         y = D.empty(n_out, "float32") if want != "pcm16" else None
         pcm = D.empty(n_out, "int16") if want != "f32" else None
         if n_out:

@@ -477,6 +477,26 @@ def test_resampler_matches_spec(A):
     np.testing.assert_allclose(y5, O.resample_48k(x, 50e6 / 521), rtol=0, atol=2e-7)
 
 
+@pytest.mark.parametrize("fs_ch", [150_000.0, 250_000.0, 192_000.0, 48_000.0, 44_100.0, 24_000.0, 8_000.0, 96_000.0, 131_071.0])
+def test_resampler_other_ratios(A, fs_ch):
+    """Channel rates other than the 96 kHz class: longer polyphase rows (the 24 / 32 / 48 taps-per-lane builds; past the
+    one-instruction window the waves read their samples straight from memory), integer ratios, rates below 48 kHz
+    (up > down: few residues, many steps) and a prime rate (up = 48000)."""
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd.processing import Resampler48k
+
+    rng = np.random.default_rng(int(fs_ch))
+    n = 30_011
+    t = np.arange(n) / fs_ch
+    x = (0.5 * np.sin(2 * np.pi * 700 * t) + 0.1 * rng.normal(size=n)).astype(np.float32)
+    rs = Resampler48k(fs_ch)
+    y, pcm = rs.process(D.to_device(x, "float32"), want="both")
+    want = O.resample_48k(x, fs_ch)
+    assert y.numel() == want.size
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=3e-7)
+    np.testing.assert_array_equal(pcm.cpu().numpy(), O.float_to_pcm16(y.cpu().numpy()))
+
+
 def test_pipeline_end_to_end_wav(A, tmp_path):
     """ProcessingPipeline.run on a WAV written to disk: result fields, 48 kHz PCM16 file, sample
     count, and the channel-rate audio against the oracle."""
