@@ -11,7 +11,7 @@ CMD="python3 $R/$SCRIPT"
 timeout -k 10 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d "$OUT/p1" -- $CMD > "$OUT/p1.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --output-format csv -d "$OUT/p2" -- $CMD > "$OUT/p2.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$OUT/p3" -- $CMD > "$OUT/p3.log" 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/p4" -- $CMD > "$OUT/p4.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d "$OUT/p4" -- $CMD > "$OUT/p4.log" 2>&1 || exit 1
 python3 - "$OUT" "$KERN" <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, sys
 from collections import defaultdict
