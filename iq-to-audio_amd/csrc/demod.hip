@@ -374,7 +374,7 @@ __global__ void k_float_to_pcm16(const float *y, long long n, short *pcm)
 // wait for vmcnt(0) in front of the next step's window -- i.e. for the store's acknowledgement.  Now the windows of the
 // next RS_AHEAD steps are in flight at any time: LDS-DMA (buffer_load_dwordx4 ... lds, ONE instruction per window,
 // range-checked: positions outside [0, n_in) arrive as zeros) into a ring of RS_RING windows per wave, no registers, and
-// ONE counted wait per step that leaves the younger windows and the stores of the last two groups of steps outstanding.
+// ONE counted wait per step that leaves the younger windows and the stores of the groups of steps behind them outstanding.
 // For that count to be exact every group of steps issues the same number of stores: unconditional buffer stores whose
 // offset is out of range in lanes that have nothing to write, and the prologue pads with dropped stores; the number of
 // younger windows is wave-uniform (it shrinks over a wave's last RS_AHEAD steps) and selects the wait.
@@ -419,10 +419,15 @@ __device__ __forceinline__ short pcm16_of_f32(float y)
 constexpr int RS_WAVES = 4;
 constexpr int RS_LANES = 4;    // lanes per output
 constexpr int RS_GROUP = 4;    // steps whose sums are reduced and stored together (= RS_LANES: one per lane of the quad)
-constexpr int RS_AHEAD = 8;    // windows in flight behind the one being read: two groups of steps
+#ifndef IQA_RS_AHEAD
+#define IQA_RS_AHEAD 8
+#endif
+constexpr int RS_AHEAD = IQA_RS_AHEAD;  // windows in flight behind the one being read, whole groups of steps (measured at
+                                         // config 2: 4 -> 28.7 us, 8 -> 29.7, 12 -> 30.9, 16 -> 33.1: not the latency any more)
 constexpr int RS_RING = RS_AHEAD + 2;  // + the one being read + the one read a step ago (its reads may still be in the LDS queue)
 constexpr unsigned int RS_NOWHERE = 0x80000000u;  // buffer offset beyond every descriptor used here: the access is dropped
-static_assert(RS_AHEAD == 2 * RS_GROUP && RS_GROUP == RS_LANES, "the counted wait assumes exactly two groups of stores per RS_AHEAD steps");
+static_assert(RS_AHEAD % RS_GROUP == 0 && RS_GROUP == RS_LANES, "the counted wait assumes whole groups of stores per RS_AHEAD steps");
+constexpr int RS_GROUPS_AHEAD = RS_AHEAD / RS_GROUP;
 
 typedef __attribute__((address_space(3))) void rs_lds_t;
 
@@ -521,8 +526,8 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(RsArgs a)
     using G = RsGeo<NI>;
     constexpr int CH = G::CHUNKS, WIN = G::WINDOW, NS = (WANT_Y ? 1 : 0) + (WANT_PCM ? 1 : 0);
     // memory operations a wave issues behind a window's DMAs before it reads that window: the DMAs of the RS_AHEAD
-    // younger windows and the stores of the two groups that ended since
-    static_assert(RS_AHEAD + 2 * NS <= 63, "vmcnt holds six bits");
+    // younger windows and the stores of the RS_AHEAD / RS_GROUP groups that ended since
+    static_assert(RS_AHEAD + RS_GROUPS_AHEAD * NS <= 63, "vmcnt holds six bits");
     static_assert(4 * NI + G::SPREAD + 3 <= WIN, "window too small for this row length");
     // (ONE LDS object on purpose: with two, hipcc tags their accesses with alias scopes and then drains vmcnt to 0 in
     // front of every read of the ring -- it knows the DMAs write there, not which of them)
@@ -593,8 +598,8 @@ __global__ __launch_bounds__(RS_WAVES *kWave) void k_resample(RsArgs a)
         ++issued;
     };
     // wait until the window of the current step has landed: behind its DMA the wave has issued the DMAs of the RS_AHEAD
-    // younger windows and the stores of two groups of steps
-    auto wait_window = [&](int) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((IQA_RS_ABLATE & 2) ? 0 : RS_AHEAD + 2 * NS) : "memory"); };
+    // younger windows and the stores of RS_AHEAD / RS_GROUP groups of steps
+    auto wait_window = [&](int) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((IQA_RS_ABLATE & 2) ? 0 : RS_AHEAD + RS_GROUPS_AHEAD * NS) : "memory"); };
     // outputs: descriptors over this wave's stretch [j_base, j_base + (g_hi - g_lo) up) of y / pcm, cut at n_out -- the
     // range check is the `jj < n_out` test and the one for the steps past g_hi of the last group; lane k of a quad
     // writes the group's step k; quads without a residue aim at RS_NOWHERE
