@@ -193,6 +193,19 @@ int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, 
                               int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
                               const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
                               int64_t n_out, void *stream);
+
+/* The same launch with TWO lanes per workgroup: lanes[2i] and lanes[2i+1] (equal q_group, n_lanes even) share every
+ * staged tile of the capture -- the workgroup's first four waves hold the tap rows of one, the other four those of
+ * the other, one tile per round: half the L2 -> LDS traffic per lane and a ring twice as deep in rounds.  Same
+ * arguments, same results bit for bit as iqa_channelize_mfma_multi on the same lanes; 8*ceil(ranges/8)*n_lanes/2
+ * workgroups.  Available where iqa_mfma_ring_pairs(fmt, D, k_first, k_count) != 0 (int16 captures, contiguous slots,
+ * 9..16 k steps: the decimations whose single-lane kernel runs without loader waves).
+ * ref: the same CLI loop over --ft targets, cli.py:683-710. */
+int iqa_channelize_mfma_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
+                              int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
+                              const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
+                              int64_t n_out, void *stream);
+int32_t iqa_mfma_ring_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count);
 /* z[m_first + i] = finish(sum_k partials_dev[k][i]): the float32 conversion, conjugation, rotation and scaling of the
  * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..8 buffers of double2[n_out],
  * or -- raw_scale != NULL -- of int32[2*n_out] written by lanes with raw_partials = 1; raw_scale is a HOST array of

@@ -346,10 +346,9 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
 
 // ---- several lanes (channels x tap-row groups) of one capture in ONE launch of the ring kernel ------------------------
 
-extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
-                                         int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
-                                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
-                                         int64_t n_out, void *stream)
+static int channelize_mfma_lanes(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t outputs_per_block,
+                                 const iqa_mfma_lane *lanes, int32_t n_lanes, const void *raw_dev, int64_t n_frames, int64_t consumed,
+                                 int64_t m_first, int64_t n_out, void *stream, bool pairs)
 {
     if (lanes == nullptr || n_lanes < 1) return fail_inval("no lanes");
     const bool u8 = fmt == IQA_FMT_U8;
@@ -366,6 +365,8 @@ extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_
     if (range <= 0 || (range & 31)) return fail_inval("outputs_per_block must be a positive multiple of 32");
     const int ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, false, u8);
     if (ring_mode == 0) return fail_inval("the ring kernel does not cover this (decimation, k-step range): see iqa_mfma_ring_mode");
+    if (pairs && !mfma_ring_pairs_supported(static_cast<int>(D), k_first, ksteps, u8))
+        return fail_inval("lane pairs are not available for this (format, decimation, k-step range): see iqa_mfma_ring_pairs");
     // every frame any lane touches must lie inside [0, n_frames): the lane with the largest tap-row group reads the
     // earliest data rows, group 0 the latest (see iqa_channelize_mfma for the geometry)
     int q_max = 0;
@@ -425,7 +426,32 @@ extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_
         l.raw_partials = (s.raw_partials != 0 && !s.finalize && !s.partial_in_dev) ? 1 : 0;
         if (s.raw_partials && !l.raw_partials) return fail_inval("raw partials need finalize == 0 and no partial_in");
     }
-    return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr);
+    return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr, pairs);
+}
+
+extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
+                                         int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
+                                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
+                                         int64_t n_out, void *stream)
+{
+    return channelize_mfma_lanes(fmt, decimation, k_first, k_count, outputs_per_block, lanes, n_lanes, raw_dev, n_frames, consumed,
+                                 m_first, n_out, stream, false);
+}
+
+extern "C" int iqa_channelize_mfma_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
+                                         int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
+                                         const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
+                                         int64_t n_out, void *stream)
+{
+    return channelize_mfma_lanes(fmt, decimation, k_first, k_count, outputs_per_block, lanes, n_lanes, raw_dev, n_frames, consumed,
+                                 m_first, n_out, stream, true);
+}
+
+extern "C" int32_t iqa_mfma_ring_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count)
+{
+    if (decimation < 1 || fmt != IQA_FMT_S16) return 0;
+    const int ks_all = (2 * decimation + 31) / 32;
+    return mfma_ring_pairs_supported(decimation, k_first, k_count > 0 ? k_count : ks_all - k_first, false) ? 1 : 0;
 }
 
 // Sum of the partial sums of a filter's tap-row groups (each written by its own lane of a multi-lane launch), then the

@@ -109,22 +109,31 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 //     row, so three passes read the capture about once instead of three times.  Always with loader waves.
 // U8 (row-staged only): uint8 I/Q captures -- a k step is 32 bytes of a row, one 16-byte fragment per lane, the
 // offset-binary bytes become int8 with one XOR, and there is a single data piece: two MFMAs per k step (q1*v, q2*v).
-template <int KS, bool ROWS, bool U8 = false>
+// PAIR (contiguous slots without loader waves only): the workgroup holds TWO lanes -- the four waves of parity 0 the tap
+// rows of one, the four of parity 1 those of the other -- and all eight read the SAME staged tile: one tile per round
+// instead of two, so the ring is twice as deep in rounds at the same LDS (five rounds instead of two at 13 k steps: the
+// refill of a slot has four rounds to land instead of one) and a tile crosses L2 -> LDS once per two lanes; two windows
+// of sums.  The lanes of a pair share their tap-row group index (the staged stream depends on it).
+template <int KS, bool ROWS, bool U8 = false, bool PAIR = false>
 struct RingGeo {
     static_assert(ROWS || !U8, "uint8 captures use row-staged slots");
+    static_assert(!PAIR || (!ROWS && !U8), "lane pairs: contiguous slots only");
+    static constexpr int TPR = PAIR ? 1 : 2;   // tiles per round
+    static constexpr int ACCS = PAIR ? 2 : 1;  // windows of sums
     static constexpr int KBYTES = U8 ? 32 : 64;  // bytes of a row per k step
     static constexpr int PITCH = KBYTES * KS + 16;
     static constexpr bool PADDED = KS <= 13;  // contiguous slots: rows at an odd pitch in LDS (conflict-free fragment reads)
     static constexpr int NI = 2 * KS + 1;  // contiguous slots: 1 KiB DMA instructions per tile (32 rows at a padded pitch)
     static constexpr int SLOT = ROWS ? 32 * PITCH : 1024 * NI;
-    static constexpr bool LOADERS = ROWS || KS <= IQA_RING_LOADERS_MAX_KS;  // two extra waves feed the ring and emit (needs <= 168 registers)
+    static constexpr bool LOADERS = !PAIR && (ROWS || KS <= IQA_RING_LOADERS_MAX_KS);  // two extra waves feed the ring and emit (needs <= 168 registers)
     static constexpr int NDMA = ROWS ? 32 : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
-    static constexpr int FIT = (160 * 1024 - RG_ACC_BYTES) / (2 * SLOT);
+    static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
     static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
     static constexpr int R = R0 > 5 ? 5 : (R0 < 2 ? 2 : R0);  // rounds of two tiles the ring holds
     static constexpr int THREADS = (RG_WAVES + (LOADERS ? 2 : 0)) * kWave;
-    static_assert(R * 2 * SLOT + RG_ACC_BYTES <= 160 * 1024, "ring + window exceed LDS");
+    static constexpr int LDS_BYTES = R * TPR * SLOT + ACCS * RG_ACC_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "ring + window exceed LDS");
     static_assert((R - 2) * NDMA <= 63, "vmcnt is a 6-bit counter");
 };
 
@@ -252,11 +261,11 @@ __device__ __forceinline__ void ring_emit_group(const MfmaArgs &a, const RingCtx
     ring_emit_store<false>(a, c, e, g);
 }
 
-template <int KS, bool ROWS, bool U8>
+template <int KS, bool ROWS, bool U8, bool PAIR = false>
 __device__ __forceinline__ void ring_wait_and_barrier(int younger)
 {
     // an issuing wave's DMAs of round r have landed once only those of the younger rounds are outstanding
-    using G = RingGeo<KS, ROWS, U8>;
+    using G = RingGeo<KS, ROWS, U8, PAIR>;
     constexpr int R = G::R, N = G::NDMA;
     if (R >= 5 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 5 ? 3 * N : 0) : "memory");
     else if (R >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R >= 4 ? 2 * N : 0) : "memory");
@@ -336,12 +345,16 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER, bool PAIR = false>
 __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
 {
-    using G = RingGeo<KS, ROWS, U8>;
+    using G = RingGeo<KS, ROWS, U8, PAIR>;
     constexpr int R = G::R, SLOT = G::SLOT;
     static_assert(!(ROWS && ISSUER), "row-staged slots are always fed by loader waves");
+    // PAIR: round r works on tile r (both parities: two lanes' tap rows), whose slot is ring slot r mod R; a lane's group k
+    // of 64 outputs (tiles 2k, 2k + 1) is emitted by that lane's emitting wave in round 2k + 5 (parity 0) / 2k + 6 (parity
+    // 1): the two lanes' emissions fall into alternate rounds
+    const int RG_EMIT_LAG_PAIR = 5 + c.cp;
     constexpr bool STREAM = ISSUER && !(DBG & 16);
     const int rt = c.rt, cp = c.cp;
     // the two issuing waves of a parity share the tile's 2*KS + 1 DMA instructions: wave p = rt & 1 issues numbers
@@ -360,7 +373,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     const int odd_kib = (rt & 1) * 1024;
     auto issue = [&](int tile, int slot, int i) {  // `i` is a compile-time constant at every call site
         const char *tile0 = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
-        char *slot0 = c.smem + (slot * 2 + cp) * SLOT;
+        char *slot0 = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT;
         const int at = (i < KS) ? odd_kib + i * 2048 : 2 * KS * 1024;  // instruction numbers p, p + 2, ..., then 2*KS
         if constexpr (ISSUER && G::PADDED) {
             __builtin_amdgcn_global_load_lds(tile0 + soff[i], (ring_lds_t *)(slot0 + at), 16, 0, IQA_RING_DMA_AUX);
@@ -372,7 +385,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
         for (int rr = 0; rr < R - 1; ++rr)
 #pragma unroll
-            for (int i = 0; i <= KS; ++i) issue(2 * rr + cp, rr, i);
+            for (int i = 0; i <= KS; ++i) issue(PAIR ? rr : 2 * rr + cp, rr, i);
     }
     RingEmit em{1.0, 0.0};
     if (EMIT && a.finalize && a.rotate) {
@@ -430,14 +443,14 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             st0 = __builtin_amdgcn_s_memtime();
             if (r) st_work += st0 - st_prev;
         }
-        if (STREAM) ring_wait_and_barrier<KS, ROWS, U8>(min(R - 2, c.rounds - 1 - r));
+        if (STREAM) ring_wait_and_barrier<KS, ROWS, U8, PAIR>(min(R - 2, c.rounds - 1 - r));
         else asm volatile("s_barrier" ::: "memory");
         if (DBG & 2) {
             st_prev = __builtin_amdgcn_s_memtime();
             st_wait += st_prev - st0;
         }
         const bool pf = STREAM && (r + R - 1 < c.rounds);
-        const int pf_tile = 2 * (r + R - 1) + cp;
+        const int pf_tile = PAIR ? r + R - 1 : 2 * (r + R - 1) + cp;
         const int pf_slot = (slot == 0) ? R - 1 : slot - 1;  // the slot round r-1 has just left
         // The refill of that slot goes out FIRST, all KS + 1 instructions of it, before this round's matrix work: at
         // 13 k steps the ring holds two rounds only, so a DMA issued late in round r (one per k step, as this loop used
@@ -448,20 +461,22 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
             for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
         }
-        const bool emit_now = EMIT && r >= RG_EMIT_LAG;
+        const bool emit_now = EMIT && (PAIR ? (r >= RG_EMIT_LAG_PAIR && ((r - RG_EMIT_LAG_PAIR) & 1) == 0) : r >= RG_EMIT_LAG);
         RingEmitRegs eg;
         if (emit_now) {
             asm volatile("" ::: "memory");
-            ring_emit_load<ACC64, true>(a, c, r - RG_EMIT_LAG, eg);  // see ring_loader for why these sums are final
+            // see ring_loader for why these sums are final (PAIR: the group's last tile was round r - 4's, whose adds --
+            // deferred by one round at most -- went out before the barrier of round r - 2)
+            ring_emit_load<ACC64, true>(a, c, PAIR ? (r - RG_EMIT_LAG_PAIR) >> 1 : r - RG_EMIT_LAG, eg);
             asm volatile("" ::: "memory");
         }
         if (DEFER_ADDS && held_t >= 0) {
             scatter(held_t, held1, held2);
             held_t = -1;
         }
-        const int t = 2 * r + cp;
+        const int t = PAIR ? r : 2 * r + cp;
         if (t < c.tiles) {
-            const char *la = c.smem + (slot * 2 + cp) * SLOT + c.lane_off;
+            const char *la = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT + c.lane_off;
             // The data fragments are read PD k steps ahead by hand (an LDS-DMA is a store to LDS as far as the compiler knows,
             // so it never moves a ds_read above an earlier issue(): the refill in front of this loop is a fence for them).
             auto tile_body = [&]() {
@@ -550,16 +565,18 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (EMIT) {
         const int k_last = (c.cnt + 62) >> 6;
-        for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k) ring_emit_group<ACC64>(a, c, em, k);
+        // the groups the loop has not emitted: PAIR emitted group k in round 2k + RG_EMIT_LAG_PAIR
+        const int k_next = PAIR ? (c.rounds > RG_EMIT_LAG_PAIR ? ((c.rounds - 1 - RG_EMIT_LAG_PAIR) >> 1) + 1 : 0) : max(c.rounds - RG_EMIT_LAG, 0);
+        for (int k = k_next; k <= k_last; ++k) ring_emit_group<ACC64>(a, c, em, k);
     }
 }
 
 // One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
 // stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
-template <int KS, int DBG, bool ACC64, bool ROWS, bool U8>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool PAIR = false>
 __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_idx)
 {
-    using G = RingGeo<KS, ROWS, U8>;
+    using G = RingGeo<KS, ROWS, U8, PAIR>;
     constexpr int R = G::R, SLOT = G::SLOT;
     constexpr bool LOADERS = G::LOADERS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -576,10 +593,11 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     c.cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - c.i0));
     c.m0 = a.m_lo + c.i0;
     c.tiles = (c.cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
-    c.rounds = (c.tiles + 1) >> 1;
+    c.rounds = PAIR ? c.tiles : (c.tiles + 1) >> 1;
     c.smem = smem;
-    c.s_acc = reinterpret_cast<int *>(smem + R * 2 * SLOT);
-    for (int i = tid; i < RG_ACC_BYTES / 4; i += G::THREADS) c.s_acc[i] = 0;
+    c.s_acc = reinterpret_cast<int *>(smem + R * G::TPR * SLOT);
+    for (int i = tid; i < G::ACCS * RG_ACC_BYTES / 4; i += G::THREADS) c.s_acc[i] = 0;
+    if (PAIR) c.s_acc += c.cp * (RG_ACC_BYTES / 4);  // each lane of the pair sums into its own window
 
     // the stream: tile t starts at data row m0 - 64 - col_shift + 32 t, i.e. frame row*D + 1
     constexpr int FB = U8 ? 2 : 4;  // bytes per frame
@@ -591,12 +609,14 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     c.pitch_units = G::PADDED ? (c.row_units | 1) : c.row_units;  // odd: conflict-free fragment reads (see RingGeo)
     c.lane_off = c.col * (ROWS ? G::PITCH : 16 * c.pitch_units) + (G::KBYTES / 2) * c.h;
 
-    if (LOADERS && wave >= RG_WAVES) {
-        c.cp = wave - RG_WAVES;
-        c.stream0 = stream;
-        __syncthreads();
-        ring_loader<KS, DBG, ACC64, ROWS, U8>(a, c);
-        return;
+    if constexpr (LOADERS) {
+        if (wave >= RG_WAVES) {
+            c.cp = wave - RG_WAVES;
+            c.stream0 = stream;
+            __syncthreads();
+            ring_loader<KS, DBG, ACC64, ROWS, U8>(a, c);
+            return;
+        }
     }
     // tap fragments of this wave's row tile: registers for the whole block
     v4i_t fq[KS][2];
@@ -612,7 +632,16 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     }
     __syncthreads();
     c.stream0 = stream;
-    if constexpr (LOADERS) {
+    if constexpr (PAIR) {
+        // parity 0's first two waves feed the ring (one tile per round: the same KS + 1 instructions per issuing wave and
+        // round as without pairs); one wave of either parity emits ITS lane's outputs; parity 1 defers its adds
+        // (waves go to SIMDs cyclically: issuers on SIMDs 0 and 1, lane A's emitter -- wave 2 -- on SIMD 2, lane B's -- wave
+        // 7 -- on SIMD 3)
+        if (c.cp == 0 && c.rt < 2) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, true>(a, c, fq);
+        else if (c.rt == 2 + c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq);
+        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, true>(a, c, fq);
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq);
+    } else if constexpr (LOADERS) {
         if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true>(a, c, fq);
         else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false>(a, c, fq);
     } else {
@@ -685,12 +714,15 @@ struct RingMultiArgs {
     RingLane lane[RG_MAX_LANES];
 };
 
-template <int KS, bool ROWS, bool U8>
+template <int KS, bool ROWS, bool U8, bool PAIR = false>
 __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
 {
     const int idx = blockIdx.x >> 3;
-    const int li = idx % m.n_lanes;  // uniform: scalar loads from the kernel-argument segment
-    const long long range_idx = static_cast<long long>(idx / m.n_lanes) * 8 + (blockIdx.x & 7);
+    // uniform: scalar loads from the kernel-argument segment.  PAIR: the table holds the pairs back to back, a workgroup
+    // takes pair (idx mod n_pairs) and its waves of parity cp (waves 4..7: cp = 1) the pair's lane cp
+    const int units = PAIR ? m.n_lanes >> 1 : m.n_lanes;
+    const int li = PAIR ? 2 * (idx % units) + ((__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) >> 2) & 1) : idx % units;
+    const long long range_idx = static_cast<long long>(idx / units) * 8 + (blockIdx.x & 7);
     const RingLane &l = m.lane[li];
     MfmaArgs a = m.c;
     a.afrag = l.afrag;
@@ -712,13 +744,20 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
     a.rotate = l.rotate;
     a.raw_partials = l.raw_partials;
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
-    ring_block<KS, 0, false, ROWS, U8>(a, range_idx);
+    ring_block<KS, 0, false, ROWS, U8, PAIR>(a, range_idx);
 }
 
 template <int KS>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_multi(RingMultiArgs m)
 {
     ring_multi_block<KS, false, false>(m);
+}
+
+// Two lanes per workgroup (RingGeo PAIR): the lanes of the table in pairs of equal tap-row group.
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, false, false, true>::THREADS), 2) void k_channelize_mfma_s16_ring_pairs(RingMultiArgs m)
+{
+    ring_multi_block<KS, false, false, true>(m);
 }
 
 template <int KS>
@@ -796,6 +835,28 @@ static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds
         }
     }
     return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[0]);
+}
+
+constexpr int RG_PAIR_MIN_KS = IQA_RING_LOADERS_MAX_KS + 1;  // lane pairs where the single-lane kernel runs without loader waves
+
+template <int KS>
+static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_t stream)
+{
+    static std::atomic<unsigned long long> done{0};
+    if constexpr (KS >= RG_PAIR_MIN_KS) {
+        using G = RingGeo<KS, false, false, true>;
+        return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS>, "k_channelize_mfma_s16_ring_pairs", G::THREADS, m, blocks, G::LDS_BYTES, stream, done);
+    } else {
+        set_error("lane pairs need at least %d k steps (got %d)", RG_PAIR_MIN_KS, KS);
+        return IQA_EINVAL;
+    }
+}
+
+bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8)
+{
+    // (15 k steps: the pair kernel would need 20 registers more than a wave has -- a spill's scratch loads would join
+    // the counted vmcnt sequence of the issuing waves)
+    return mfma_ring_mode(decimation, k_first, k_count, false, u8) == 1 && k_count >= RG_PAIR_MIN_KS && k_count != 15;
 }
 
 constexpr int RG_ROWS_MAX_KS = RG_ROWS_MAX_KS_C;  // 8*KS tap registers + the rest must stay within 168 (three waves on two SIMDs)
@@ -908,11 +969,22 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
 // Several lanes (channels x tap-row groups) of one capture in one launch; int32 sums only.  `lanes` holds n_lanes
 // entries whose fields mirror the per-lane part of MfmaArgs; `a` carries what they share.
 int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes, size_t lds, hipStream_t stream, bool rows, bool u8,
-                           unsigned *blocks_out)
+                           unsigned *blocks_out, bool pairs)
 {
     if (n_lanes < 1 || n_lanes > RG_MAX_LANES) {
         set_error("a multi-lane launch takes 1..%d lanes (got %d)", RG_MAX_LANES, n_lanes);
         return IQA_EINVAL;
+    }
+    if (pairs) {
+        if (rows || u8 || (n_lanes & 1)) {
+            set_error("lane pairs: contiguous int16 slots and an even number of lanes");
+            return IQA_EINVAL;
+        }
+        for (int i = 0; i < n_lanes; i += 2)
+            if (lanes[i].col_shift != lanes[i + 1].col_shift) {
+                set_error("lane pairs: lanes %d and %d belong to different tap-row groups", i, i + 1);
+                return IQA_EINVAL;
+            }
     }
     RingMultiArgs m;
     m.c = a;
@@ -942,8 +1014,18 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
     for (int i = n_lanes; i < RG_MAX_LANES; ++i) m.lane[i] = m.lane[0];
     const long long ranges = (a.n_out + a.range - 1) / a.range;
     const long long groups = (ranges + 7) / 8;  // ranges are dealt to the 8 XCD classes: workgroup b -> class b % 8
-    const unsigned blocks = static_cast<unsigned>(groups * n_lanes * 8);
+    const unsigned blocks = static_cast<unsigned>(groups * (pairs ? n_lanes / 2 : n_lanes) * 8);
     if (blocks_out) *blocks_out = blocks;
+    if (pairs) {
+        switch (a.ksteps) {
+#define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream)
+            RG_PAIRS(9); RG_PAIRS(10); RG_PAIRS(11); RG_PAIRS(12); RG_PAIRS(13); RG_PAIRS(14); RG_PAIRS(16);
+#undef RG_PAIRS
+            default: break;
+        }
+        set_error("lane pairs: %d k steps not instantiated (9..14, 16)", a.ksteps);
+        return IQA_EINVAL;
+    }
     switch (a.ksteps) {
 #define RG_MULTI(K) case K: return ring_launch_multi<K>(m, blocks, lds, stream, rows, u8)
         RG_MULTI(1); RG_MULTI(2); RG_MULTI(3); RG_MULTI(4); RG_MULTI(5); RG_MULTI(6); RG_MULTI(7); RG_MULTI(8);

@@ -549,6 +549,7 @@ class ChannelBank:
     """
 
     MAX_LANES = 16  # per launch (the lane table travels as kernel arguments)
+    pair_lanes = True  # two lanes of equal tap-row group per workgroup where the kernel offers it (see _run_shared)
 
     def __init__(self, channelizers: list):
         if not channelizers:
@@ -647,9 +648,11 @@ class ChannelBank:
         partial = {key: D.empty(2 * n_int, "int32" if raw else "float64") for key, needed in need_partial.items() if needed}
         cpx = max(1, _ChannelKernel.launch_blocks // 8)  # CUs per XCD class the launch may fill
         launches = 0
-        for lo in range(0, len(ids), self.MAX_LANES):
-            part = ids[lo : lo + self.MAX_LANES]
-            ranges = 8 * max(1, cpx // len(part))
+
+        def launch(part, entry: str, units: int) -> None:
+            """One launch per k-step range for the lanes ``part``; ``units`` workgroups share a stretch of the capture."""
+            nonlocal launches
+            ranges = 8 * max(1, cpx // units)
             rng = max(128, -(-(-(-n_int // ranges)) // 32) * 32)
             for ri, (k_first, k_count) in enumerate(kranges):
                 last_range = ri == len(kranges) - 1
@@ -670,10 +673,28 @@ class ChannelBank:
                     lane.q_group, lane.finalize = gi, int(fin)
                     lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
                     lane.raw_partials = int(raw and not fin)
-                N.call("iqa_channelize_mfma_multi", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first),
-                       c_int32(k_count), c_int32(rng), table, c_int32(len(part)), N.ptr(big), c_int64(big_frames),
-                       c_int64(big_consumed), c_int64(m_a), c_int64(n_int), N.stream_ptr())
+                N.call(entry, c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first), c_int32(k_count), c_int32(rng),
+                       table, c_int32(len(part)), N.ptr(big), c_int64(big_frames), c_int64(big_consumed), c_int64(m_a), c_int64(n_int),
+                       N.stream_ptr())
                 launches += 1
+
+        # Lanes of equal tap-row group go two to a workgroup where the kernel offers it (contiguous ring slots without
+        # loader waves: 9..16 k steps): both read every staged tile of the capture -- half the L2 -> LDS traffic per
+        # lane and a ring twice as deep in rounds.  What is left over (a group with an odd number of lanes) runs one lane
+        # per workgroup as before.
+        paired, singles = [], list(ids)
+        if self.pair_lanes and len(kranges) == 1 and N.lib().iqa_mfma_ring_pairs(P.FMT_CODE[self.fmt], self.decimation, *kranges[0]):
+            singles = []
+            for gi in sorted({g for _, g in ids}):
+                members = [i for i in ids if i[1] == gi]
+                paired += members[: len(members) // 2 * 2]
+                singles += members[len(members) // 2 * 2 :]
+        for lo in range(0, len(paired), self.MAX_LANES):
+            part = paired[lo : lo + self.MAX_LANES]
+            launch(part, "iqa_channelize_mfma_pairs", len(part) // 2)
+        for lo in range(0, len(singles), self.MAX_LANES):
+            part = singles[lo : lo + self.MAX_LANES]
+            launch(part, "iqa_channelize_mfma_multi", len(part))
         combines = 0
         for ci, mp in enumerate(plans):
             if len(mp.groups) > 1:
@@ -688,7 +709,7 @@ class ChannelBank:
                 N.call("iqa_mfma_combine", byref(kernels[ci].params), ptrs, c_int32(len(mp.groups)), scale, c_int64(m_a),
                        c_int64(n_int), N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
                 combines += 1
-        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines)
+        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines, pairs=len(paired) // 2)
         return zs
 
 

@@ -34,8 +34,9 @@ def make():
 
 def run(mode):
     chans = make()
-    if mode == "bank":
+    if mode in ("bank", "nopair"):  # nopair: one lane per workgroup throughout (the launch before lane pairs existed)
         bank = A.ChannelBank(chans)
+        bank.pair_lanes = mode == "bank"
         zs = bank.process(raw, outs=outs, last_block=True, halo=(buf, 0))
         return zs, bank.last_launch
     return [c.process(raw, out_dev=o, last_block=True, halo=(buf, 0)) for c, o in zip(chans, outs)], None
@@ -57,7 +58,7 @@ for mode in modes:
     algo = 4.0 * n_total + len(targets) * 8.0 * n_dec
     print(f"{which} {mode}: {ms:.3f} ms per capture of {n_total/1e6:.0f} M frames ({len(targets)} channels, D={d}) = {n_total/ms/1e6:.1f} GS/s of capture; "
           f"algorithmic {algo/1e9:.2f} GB -> {algo/ms/1e6:.0f} GB/s = {algo/ms/1e6/8000:.3f} of 8 TB/s; launch info {info}", flush=True)
-if len(keep) == 2:
+if "bank" in keep and "single" in keep:
     e = 1024  # (the first and last outputs come from each channel's float32 kernel; a bank's common interior is a little shorter)
     print("bank vs single inside the common matrix-core interior: max |diff| =",
           max(float((a[e:-e] - b[e:-e]).abs().max()) for a, b in zip(keep["bank"], keep["single"])),

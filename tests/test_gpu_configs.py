@@ -381,7 +381,16 @@ def test_channel_bank_equals_one_channel_at_a_time(A, fs, fmt, specs, n):
         PR._ChannelKernel.mfma_min_outputs = old_min
     groups = [max(1, -(-(-(-len(A.design_channel_filter(fs, bw, d)) // d)) // 64)) for _, bw, _ in specs]
     kranges = 1 if (d % 4 == 0 and d <= 256 and fmt == "s16") else -(-(-(-2 * d // 32)) // 11)
-    assert info == dict(lanes=sum(groups), launches=kranges, combines=sum(g > 1 for g in groups)), info
+    # lanes of equal tap-row group go two to a workgroup where the kernel offers it (int16, contiguous slots, 9..16 k steps)
+    ks = -(-2 * d // 32)
+    per_group = [sum(1 for g in groups if g > gi) for gi in range(max(groups))]
+    can_pair = fmt == "s16" and d % 4 == 0 and 9 <= ks <= 16 and ks != 15
+    pairs = sum(c // 2 for c in per_group) if can_pair else 0
+    left = sum(groups) - 2 * pairs
+    launches = (kranges if left else 0) + (1 if pairs else 0)
+    assert info == dict(lanes=sum(groups), launches=launches, combines=sum(g > 1 for g in groups), pairs=pairs), info
+    if fs == 20e6:
+        assert (pairs, left) == (4, 2)
     # The matrix-core interior of a block starts 64 outputs per tap-row group behind the block's first output and ends
     # ~30 outputs before its last: a bank uses the interior common to its channels, so a channel with fewer groups gets
     # a few more of its first outputs from the float32 kernel than it would alone.  Inside: bit-identical.
@@ -432,7 +441,7 @@ def test_resident_bank_runner_matches_the_oracle_per_target(A):
     devs = [D.to_device(c.reshape(-1), "int16") for c in caps]
     torch.cuda.synchronize()
     tickets = [runner.submit(x) for x in devs]
-    assert tickets[0]["launch"] == dict(lanes=1 + 2 + 5 + 1, launches=1, combines=2)  # 6401 / 8001 / 28571 / 6401 taps at D = 104
+    assert tickets[0]["launch"] == dict(lanes=1 + 2 + 5 + 1, launches=1, combines=2, pairs=0)  # (7 k steps: no lane pairs) 6401 / 8001 / 28571 / 6401 taps at D = 104
     for cap, ticket in zip(caps, tickets):
         res = runner.collect(ticket)
         for spec, r in zip(targets, res):
