@@ -194,11 +194,13 @@ int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, 
                               const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
                               int64_t n_out, void *stream);
 
-/* The same launch with TWO lanes per workgroup: lanes[2i] and lanes[2i+1] (equal q_group, n_lanes even) share every
- * staged tile of the capture -- the workgroup's first four waves hold the tap rows of one, the other four those of
- * the other, one tile per round: half the L2 -> LDS traffic per lane and a ring twice as deep in rounds.  Same
- * arguments, same results bit for bit as iqa_channelize_mfma_multi on the same lanes; 8*ceil(ranges/8)*n_lanes/2
- * workgroups.  Available where iqa_mfma_ring_pairs(fmt, D, k_first, k_count) != 0 (int16 captures, contiguous slots,
+/* The same launch with TWO lanes per workgroup: lanes[2i] and lanes[2i+1] (n_lanes even) share every staged tile of the
+ * capture -- the workgroup's first four waves hold the tap rows of one, the other four those of the other, one tile
+ * per round: half the L2 -> LDS traffic per lane and a ring twice as deep in rounds.  lanes[2i].q_group >=
+ * lanes[2i+1].q_group (the first lane's stream is the one staged; the second works two rounds per group of difference
+ * behind); lanes[2i+1].afrag_dev may be NULL: a pair without a second lane (that half of the workgroup idles).  Same
+ * arguments otherwise, same results bit for bit as iqa_channelize_mfma_multi on the same lanes;
+ * 8*ceil(ranges/8)*n_lanes/2 workgroups.  Available where iqa_mfma_ring_pairs(fmt, D, k_first, k_count) != 0 (int16 captures, contiguous slots,
  * 9..16 k steps: the decimations whose single-lane kernel runs without loader waves).
  * ref: the same CLI loop over --ft targets, cli.py:683-710. */
 int iqa_channelize_mfma_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,

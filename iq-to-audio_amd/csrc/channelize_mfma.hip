@@ -372,7 +372,10 @@ static int channelize_mfma_lanes(int32_t fmt, int32_t decimation, int32_t k_firs
     int q_max = 0;
     for (int i = 0; i < n_lanes; ++i) {
         if (lanes[i].q_group < 0) return fail_inval("bad q group");
-        if (!lanes[i].afrag_dev) return fail_inval("lane without tap fragments");
+        if (!lanes[i].afrag_dev) {
+            if (pairs && (i & 1)) continue;  // a pair without a second lane: that half of the workgroup idles
+            return fail_inval("lane without tap fragments");
+        }
         if (lanes[i].finalize ? !lanes[i].z_out_dev : !lanes[i].partial_out_dev) return fail_inval("lane without an output buffer");
         q_max = lanes[i].q_group > q_max ? lanes[i].q_group : q_max;
     }

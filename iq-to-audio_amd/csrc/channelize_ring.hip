@@ -87,6 +87,7 @@ constexpr int RG_EMIT_WAVE = 2;  // (rt 2, parity 0): not an issuing wave
 // is already multiplying -- the two waves of a SIMD then alternate between the matrix pipe and the LDS instead of
 // meeting in both), so a group of 64 outputs is final three rounds after its first tile.
 constexpr int RG_EMIT_LAG = 3;
+constexpr int RG_PAIR_IDLE = 1 << 28;  // MfmaArgs::pair_shift of the half of a pair that has no lane
 
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
@@ -145,6 +146,7 @@ struct RingCtx {
     long long tile_bytes, i0, m0;
     int tiles, rounds, cnt, lane_off, rt, cp, col, h, lane;
     int row_units, pitch_units;  // contiguous slots: 16-byte units per data row in the capture / in LDS (odd)
+    int tshift;  // lane pairs: this wave's own tile t is the staged tile of round t + tshift (0 without pairs)
 };
 
 // Source offset (bytes from the tile's first byte) of the 16 bytes lane `lane` of DMA instruction `idx` fetches: the
@@ -372,7 +374,8 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     }
     const int odd_kib = (rt & 1) * 1024;
     auto issue = [&](int tile, int slot, int i) {  // `i` is a compile-time constant at every call site
-        const char *tile0 = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
+        // (PAIR: the stream runs on past this lane's own last tile for the partner that works pair_extra rounds behind)
+        const char *tile0 = c.stream0 + static_cast<long long>(min(tile, (PAIR ? c.rounds : c.tiles) - 1)) * c.tile_bytes;
         char *slot0 = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT;
         const int at = (i < KS) ? odd_kib + i * 2048 : 2 * KS * 1024;  // instruction numbers p, p + 2, ..., then 2*KS
         if constexpr (ISSUER && G::PADDED) {
@@ -461,21 +464,22 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
             for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
         }
-        const bool emit_now = EMIT && (PAIR ? (r >= RG_EMIT_LAG_PAIR && ((r - RG_EMIT_LAG_PAIR) & 1) == 0) : r >= RG_EMIT_LAG);
+        const int re = r - c.tshift;  // PAIR: the round in this lane's own count (its tile re is staged now)
+        const bool emit_now = EMIT && (PAIR ? (re >= RG_EMIT_LAG_PAIR && ((re - RG_EMIT_LAG_PAIR) & 1) == 0) : r >= RG_EMIT_LAG);
         RingEmitRegs eg;
         if (emit_now) {
             asm volatile("" ::: "memory");
             // see ring_loader for why these sums are final (PAIR: the group's last tile was round r - 4's, whose adds --
             // deferred by one round at most -- went out before the barrier of round r - 2)
-            ring_emit_load<ACC64, true>(a, c, PAIR ? (r - RG_EMIT_LAG_PAIR) >> 1 : r - RG_EMIT_LAG, eg);
+            ring_emit_load<ACC64, true>(a, c, PAIR ? (re - RG_EMIT_LAG_PAIR) >> 1 : r - RG_EMIT_LAG, eg);
             asm volatile("" ::: "memory");
         }
         if (DEFER_ADDS && held_t >= 0) {
             scatter(held_t, held1, held2);
             held_t = -1;
         }
-        const int t = PAIR ? r : 2 * r + cp;
-        if (t < c.tiles) {
+        const int t = PAIR ? re : 2 * r + cp;
+        if (t >= 0 && t < c.tiles) {
             const char *la = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT + c.lane_off;
             // The data fragments are read PD k steps ahead by hand (an LDS-DMA is a store to LDS as far as the compiler knows,
             // so it never moves a ds_read above an earlier issue(): the refill in front of this loop is a fence for them).
@@ -566,8 +570,10 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     if (EMIT) {
         const int k_last = (c.cnt + 62) >> 6;
         // the groups the loop has not emitted: PAIR emitted group k in round 2k + RG_EMIT_LAG_PAIR
-        const int k_next = PAIR ? (c.rounds > RG_EMIT_LAG_PAIR ? ((c.rounds - 1 - RG_EMIT_LAG_PAIR) >> 1) + 1 : 0) : max(c.rounds - RG_EMIT_LAG, 0);
-        for (int k = k_next; k <= k_last; ++k) ring_emit_group<ACC64>(a, c, em, k);
+        const int own = c.rounds - c.tshift;  // rounds in this lane's own count
+        const int k_next = PAIR ? (own > RG_EMIT_LAG_PAIR ? ((own - 1 - RG_EMIT_LAG_PAIR) >> 1) + 1 : 0) : max(c.rounds - RG_EMIT_LAG, 0);
+        if (!PAIR || c.tshift < RG_PAIR_IDLE)  // (the idle half of a pair without a second lane emits nothing)
+            for (int k = k_next; k <= k_last; ++k) ring_emit_group<ACC64>(a, c, em, k);
     }
 }
 
@@ -593,7 +599,8 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     c.cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - c.i0));
     c.m0 = a.m_lo + c.i0;
     c.tiles = (c.cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
-    c.rounds = PAIR ? c.tiles : (c.tiles + 1) >> 1;
+    c.rounds = PAIR ? c.tiles + a.pair_extra : (c.tiles + 1) >> 1;
+    c.tshift = PAIR ? a.pair_shift : 0;  // (RG_PAIR_IDLE: the idle half of a pair without a second lane -- barriers only)
     c.smem = smem;
     c.s_acc = reinterpret_cast<int *>(smem + R * G::TPR * SLOT);
     for (int i = tid; i < G::ACCS * RG_ACC_BYTES / 4; i += G::THREADS) c.s_acc[i] = 0;
@@ -725,6 +732,7 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
     const long long range_idx = static_cast<long long>(idx / units) * 8 + (blockIdx.x & 7);
     const RingLane &l = m.lane[li];
     MfmaArgs a = m.c;
+    a.pair_shift = a.pair_extra = 0;
     a.afrag = l.afrag;
     a.out = l.out;
     a.partial_in = l.partial_in;
@@ -743,6 +751,18 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
     a.conj_sum = l.conj_sum;
     a.rotate = l.rotate;
     a.raw_partials = l.raw_partials;
+    if constexpr (PAIR) {
+        // the pair's first lane has the larger (or the same) tap-row group: ITS stream is staged, the second lane's own
+        // tiles arrive 2 rounds per group of difference later; a pair without a second lane (afrag NULL) idles that half
+        const RingLane &la = m.lane[li & ~1], &lb = m.lane[li | 1];
+        const bool idle_b = lb.afrag == nullptr;
+        a.pair_extra = idle_b ? 0 : (la.col_shift - lb.col_shift) >> 5;
+        a.col_shift = la.col_shift;
+        if (li & 1) {
+            a.pair_shift = idle_b ? RG_PAIR_IDLE : a.pair_extra;
+            if (idle_b) a.afrag = la.afrag;  // (anything readable: the fragments are loaded, never used)
+        }
+    }
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
     ring_block<KS, 0, false, ROWS, U8, PAIR>(a, range_idx);
 }
@@ -981,8 +1001,8 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
             return IQA_EINVAL;
         }
         for (int i = 0; i < n_lanes; i += 2)
-            if (lanes[i].col_shift != lanes[i + 1].col_shift) {
-                set_error("lane pairs: lanes %d and %d belong to different tap-row groups", i, i + 1);
+            if (lanes[i].afrag == nullptr || (lanes[i + 1].afrag != nullptr && lanes[i].col_shift < lanes[i + 1].col_shift)) {
+                set_error("lane pairs: lane %d must exist and have the larger (or the same) tap-row group of its pair", i);
                 return IQA_EINVAL;
             }
     }

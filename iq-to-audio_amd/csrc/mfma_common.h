@@ -35,6 +35,10 @@ struct MfmaArgs {
     float sc_re, sc_im;
     double rot64_re, rot64_im;  // exp(j*2*pi*64*rot_step): rotation between outputs 64 apart (ring kernel emission)
     int raw_partials;  // ring kernels, int32 sums, finalize == 0, no partial_in: partial_out holds int2 {256*S1+S2 re, im} (8 B per output)
+    // lane pairs (ring kernel, two lanes per workgroup): this lane's own tile t is staged in round t + pair_shift (the
+    // stream is the one of the pair's lane with the LARGER tap-row group, which starts 2 tiles earlier per group), and
+    // the workgroup runs pair_extra rounds beyond a lane's own tiles
+    int pair_shift, pair_extra;
 };
 
 // The last steps of every matrix-core emission, written with explicit roundings so that the kernels that share them

@@ -657,7 +657,10 @@ class ChannelBank:
             for ri, (k_first, k_count) in enumerate(kranges):
                 last_range = ri == len(kranges) - 1
                 table = (N.MfmaLane * len(part))()
-                for lane, (ci, gi) in zip(table, part):
+                for lane, ident in zip(table, part):
+                    if ident is None:  # the empty half of an odd pair: a zeroed entry
+                        continue
+                    ci, gi = ident
                     k, mp = kernels[ci], plans[ci]
                     ps = next(p_ for p_ in mp.passes if p_.group == gi and p_.k_first == k_first)
                     fin = last_range and len(mp.groups) == 1
@@ -678,23 +681,24 @@ class ChannelBank:
                        N.stream_ptr())
                 launches += 1
 
-        # Lanes of equal tap-row group go two to a workgroup where the kernel offers it (contiguous ring slots without
-        # loader waves: 9..16 k steps): both read every staged tile of the capture -- half the L2 -> LDS traffic per
-        # lane and a ring twice as deep in rounds.  What is left over (a group with an odd number of lanes) runs one lane
-        # per workgroup as before.
-        paired, singles = [], list(ids)
+        # Two lanes to a workgroup where the kernel offers it (contiguous ring slots without loader waves: 9..16 k steps):
+        # both read every staged tile of the capture -- half the L2 -> LDS traffic per lane and a ring twice as deep in
+        # rounds.  A pair's first lane has the larger (or the same) tap-row group: lanes in descending group order, two
+        # by two; an odd lane out shares its workgroup with nobody (None).  ONE launch either way: the capture crosses
+        # HBM once.
         if self.pair_lanes and len(kranges) == 1 and N.lib().iqa_mfma_ring_pairs(P.FMT_CODE[self.fmt], self.decimation, *kranges[0]):
-            singles = []
-            for gi in sorted({g for _, g in ids}):
-                members = [i for i in ids if i[1] == gi]
-                paired += members[: len(members) // 2 * 2]
-                singles += members[len(members) // 2 * 2 :]
-        for lo in range(0, len(paired), self.MAX_LANES):
-            part = paired[lo : lo + self.MAX_LANES]
-            launch(part, "iqa_channelize_mfma_pairs", len(part) // 2)
-        for lo in range(0, len(singles), self.MAX_LANES):
-            part = singles[lo : lo + self.MAX_LANES]
-            launch(part, "iqa_channelize_mfma_multi", len(part))
+            paired = sorted(ids, key=lambda i: -i[1])
+            if len(paired) & 1:
+                paired.append(None)
+            for lo in range(0, len(paired), self.MAX_LANES):
+                part = paired[lo : lo + self.MAX_LANES]
+                launch(part, "iqa_channelize_mfma_pairs", len(part) // 2)
+            n_pairs = len(paired) // 2
+        else:
+            n_pairs = 0
+            for lo in range(0, len(ids), self.MAX_LANES):
+                part = ids[lo : lo + self.MAX_LANES]
+                launch(part, "iqa_channelize_mfma_multi", len(part))
         combines = 0
         for ci, mp in enumerate(plans):
             if len(mp.groups) > 1:
@@ -709,7 +713,7 @@ class ChannelBank:
                 N.call("iqa_mfma_combine", byref(kernels[ci].params), ptrs, c_int32(len(mp.groups)), scale, c_int64(m_a),
                        c_int64(n_int), N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
                 combines += 1
-        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines, pairs=len(paired) // 2)
+        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines, pairs=n_pairs)
         return zs
 
 

@@ -341,6 +341,10 @@ def test_config5_unit_five_nfm_channels(A, tmp_path):
 @pytest.mark.parametrize("fs,fmt,specs,n", [
     # C3: D = 208, contiguous slots, 1 + 2 + 3 + 3 + 1 tap-row groups = 10 lanes, three filters finished by the combine kernel
     (20e6, "s16", [(25e3, 12_500.0, 1), (-150e3, 10_000.0, 1), (400e3, 2_800.0, 1), (-1.1e6, 2_800.0, -1), (2.3e6, 12_500.0, 1)], 12_000_000),
+    # D = 208, lane pairs across tap-row groups: 1 + 3 + 2 groups = 6 lanes in descending group order (2,1), (1,0), (0,0)
+    (20e6, "s16", [(25e3, 12_500.0, 1), (400e3, 2_800.0, -1), (-150e3, 10_000.0, 1)], 9_000_000),
+    # D = 208, an odd number of lanes: one pair and a workgroup whose second half idles
+    (20e6, "s16", [(25e3, 12_500.0, 1), (-1.3e6, 12_500.0, -1), (2.3e6, 12_500.0, 1)], 9_000_000),
     # C2 rate: D = 104 (loader waves), three single-group lanes
     (10e6, "s16", [(25e3, 12_500.0, 1), (-1.3e6, 12_500.0, 1), (3.1e6, 12_500.0, -1)], 7_000_000),
     # C5's unit: D = 521, row-staged slots, five channels x three k-step passes chained through partial sums
@@ -383,14 +387,11 @@ def test_channel_bank_equals_one_channel_at_a_time(A, fs, fmt, specs, n):
     kranges = 1 if (d % 4 == 0 and d <= 256 and fmt == "s16") else -(-(-(-2 * d // 32)) // 11)
     # lanes of equal tap-row group go two to a workgroup where the kernel offers it (int16, contiguous slots, 9..16 k steps)
     ks = -(-2 * d // 32)
-    per_group = [sum(1 for g in groups if g > gi) for gi in range(max(groups))]
     can_pair = fmt == "s16" and d % 4 == 0 and 9 <= ks <= 16 and ks != 15
-    pairs = sum(c // 2 for c in per_group) if can_pair else 0
-    left = sum(groups) - 2 * pairs
-    launches = (kranges if left else 0) + (1 if pairs else 0)
-    assert info == dict(lanes=sum(groups), launches=launches, combines=sum(g > 1 for g in groups), pairs=pairs), info
+    pairs = -(-sum(groups) // 2) if can_pair else 0  # lanes in descending group order, two by two; one launch either way
+    assert info == dict(lanes=sum(groups), launches=kranges, combines=sum(g > 1 for g in groups), pairs=pairs), info
     if fs == 20e6:
-        assert (pairs, left) == (4, 2)
+        assert pairs == {10: 5, 6: 3, 3: 2}[sum(groups)]
     # The matrix-core interior of a block starts 64 outputs per tap-row group behind the block's first output and ends
     # ~30 outputs before its last: a bank uses the interior common to its channels, so a channel with fewer groups gets
     # a few more of its first outputs from the float32 kernel than it would alone.  Inside: bit-identical.
