@@ -65,8 +65,12 @@
 #ifndef IQA_RING_STAGGER
 #define IQA_RING_STAGGER 0
 #endif
+#ifndef IQA_RING_PAIR_ROUNDS
+#define IQA_RING_PAIR_ROUNDS 5  // ring depth of the lane-pair kernel in rounds (2..5)
+#endif
 
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <type_traits>
 
@@ -87,6 +91,9 @@ constexpr int RG_EMIT_WAVE = 2;  // (rt 2, parity 0): not an issuing wave
 // is already multiplying -- the two waves of a SIMD then alternate between the matrix pipe and the LDS instead of
 // meeting in both), so a group of 64 outputs is final three rounds after its first tile.
 constexpr int RG_EMIT_LAG = 3;
+constexpr unsigned int RG_PACE_AHEAD = 2;  // publications (of every second round) a workgroup may be in front of its range's slowest
+constexpr int RG_PACE_SPINS = 20000;
+constexpr int RG_PACE_WORDS = 16384;       // words of the pacing buffer: ranges x units of a launch must fit
 constexpr int RG_PAIR_IDLE = 1 << 28;  // MfmaArgs::pair_shift of the half of a pair that has no lane
 
 __device__ __forceinline__ unsigned lds_addr(const void *p)
@@ -131,7 +138,8 @@ struct RingGeo {
     static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
     static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
-    static constexpr int R = R0 > 5 ? 5 : (R0 < 2 ? 2 : R0);  // rounds of two tiles the ring holds
+    static constexpr int RCAP = PAIR ? IQA_RING_PAIR_ROUNDS : 5;
+    static constexpr int R = R0 > RCAP ? RCAP : (R0 < 2 ? 2 : R0);  // rounds (of two tiles; PAIR: of one) the ring holds
     static constexpr int THREADS = (RG_WAVES + (LOADERS ? 2 : 0)) * kWave;
     static constexpr int LDS_BYTES = R * TPR * SLOT + ACCS * RG_ACC_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "ring + window exceed LDS");
@@ -440,6 +448,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     // DBG & 2 (diagnostic builds): per wave, cycles spent waiting in front of / at the round barrier and cycles between
     // barriers, summed over the rounds -> a.stamps[(workgroup * 8 + wave) * 4 + {0: wait, 1: work, 2: rounds, 3: first tile stamp}]
     unsigned long long st_wait = 0, st_work = 0, st_prev = 0;
+    bool pace_on = PAIR && a.pace != nullptr && a.pace_units > 1 && c.rounds < 8000;
     for (int r = 0; r < c.rounds; ++r) {
         unsigned long long st0 = 0;
         if (DBG & 2) {
@@ -451,6 +460,36 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         if (DBG & 2) {
             st_prev = __builtin_amdgcn_s_memtime();
             st_wait += st_prev - st0;
+        }
+        if constexpr (PAIR && !ISSUER && !EMIT && !DEFER) {
+            // Pacing (wave rt 3 of parity 0: no counted waits of its own to disturb).  The workgroups of a range share the
+            // capture through their XCD's L2, which at this rate keeps a line for ~10 us = a few rounds; single-lane
+            // workgroups stay that close by themselves (the one in front misses in L2 and waits for HBM, the others hit),
+            // a pair's DMAs are off its critical path and nothing holds the workgroups of a range together: 1.9x - 4.3x
+            // the capture in HBM reads.  So every second round a workgroup publishes its round and the one that is more
+            // than RG_PACE_AHEAD publications in front of the slowest STARTED workgroup of its range waits for it -- the
+            // slowest never waits, a workgroup that has not started is not waited for: no cycle.
+            if (c.rt == 3 && pace_on && (r & 1) == 0) {
+                const unsigned int mine = static_cast<unsigned int>(r >> 1);
+                if (c.lane == 0) __hip_atomic_store(a.pace + a.pace_slot, (a.pace_token << 12) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0;; ++spin) {
+                    unsigned int q = mine;
+                    if (c.lane < a.pace_units) {
+                        const unsigned int v = __hip_atomic_load(a.pace + (a.pace_slot - a.pace_slot % a.pace_units) + c.lane, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                        if ((v >> 12) == a.pace_token) q = v & 0xFFFu;
+                    }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) q = min(q, static_cast<unsigned int>(__shfl_xor(static_cast<int>(q), o, kWave)));
+                    q = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(q)));
+                    if (mine <= q + RG_PACE_AHEAD) break;
+                    if (spin >= RG_PACE_SPINS) {  // (a peer that stopped moving: do without)
+                        pace_on = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+            }
         }
         const bool pf = STREAM && (r + R - 1 < c.rounds);
         const int pf_tile = PAIR ? r + R - 1 : 2 * (r + R - 1) + cp;
@@ -762,6 +801,8 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
             a.pair_shift = idle_b ? RG_PAIR_IDLE : a.pair_extra;
             if (idle_b) a.afrag = la.afrag;  // (anything readable: the fragments are loaded, never used)
         }
+        a.pace_units = units;
+        a.pace_slot = static_cast<int>(range_idx) * units + idx % units;
     }
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
     ring_block<KS, 0, false, ROWS, U8, PAIR>(a, range_idx);
@@ -870,6 +911,30 @@ static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_
         set_error("lane pairs need at least %d k steps (got %d)", RG_PAIR_MIN_KS, KS);
         return IQA_EINVAL;
     }
+}
+
+// The pacing words of the lane-pair launches (RG_PACE_WORDS x 4 bytes per device, allocated and cleared at the first pair
+// launch on that device -- not inside a stream capture -- and never freed: library state, see the header's conventions).
+// Entries carry the launch's token, so nothing is reset between launches.
+static unsigned int *ring_pace_buffer(unsigned int &token)
+{
+    static std::mutex mu;
+    static unsigned int *buf[64] = {};
+    static unsigned int next_token = 1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    token = next_token = (next_token % 0xFFFFFu) + 1;
+    unsigned int *&b = buf[dev & 63];
+    if (b == nullptr) {
+        void *p = nullptr;
+        if (hipMalloc(&p, RG_PACE_WORDS * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, RG_PACE_WORDS * sizeof(unsigned int)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;  // (the launch runs unpaced: correct, only its workgroups may drift apart)
+        }
+        b = static_cast<unsigned int *>(p);
+    }
+    return b;
 }
 
 bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8)
@@ -1037,6 +1102,8 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
     const unsigned blocks = static_cast<unsigned>(groups * (pairs ? n_lanes / 2 : n_lanes) * 8);
     if (blocks_out) *blocks_out = blocks;
     if (pairs) {
+        m.c.pace = nullptr;
+        if (groups * 8 * (n_lanes / 2) <= RG_PACE_WORDS) m.c.pace = ring_pace_buffer(m.c.pace_token);
         switch (a.ksteps) {
 #define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream)
             RG_PAIRS(9); RG_PAIRS(10); RG_PAIRS(11); RG_PAIRS(12); RG_PAIRS(13); RG_PAIRS(14); RG_PAIRS(16);

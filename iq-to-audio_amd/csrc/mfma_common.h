@@ -39,6 +39,11 @@ struct MfmaArgs {
     // stream is the one of the pair's lane with the LARGER tap-row group, which starts 2 tiles earlier per group), and
     // the workgroup runs pair_extra rounds beyond a lane's own tiles
     int pair_shift, pair_extra;
+    // lane pairs: pacing of the workgroups that stream the same range (see ring_main): a word per (range, unit) in a
+    // library-owned device buffer, tagged with this launch's token
+    unsigned int *pace;
+    unsigned int pace_token;
+    int pace_slot, pace_units;
 };
 
 // The last steps of every matrix-core emission, written with explicit roundings so that the kernels that share them

@@ -7,6 +7,9 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 import iq_to_audio_amd as A
+from iq_to_audio_amd import _native as NATIVE
+if os.environ.get("IQA_LIB"):  # an experiment build of the library
+    NATIVE.LIB_PATH = Path(os.environ["IQA_LIB"]).resolve()
 from iq_to_audio_amd import _dev as D, dsp_plan as P
 from iq_to_audio_amd.batch import ResidentCaptureRunner
 from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
@@ -16,11 +19,14 @@ modes = sys.argv[2:] or ["bank", "single"]
 if which == "c3":
     fs, secs, uniq = 20e6, 60.0, 2.0
     targets = [(25e3, "nfm", 12500.0), (-150e3, "am", 10000.0), (400e3, "usb", 2800.0), (-1.1e6, "lsb", 2800.0), (2.3e6, "nfm", 12500.0)]
+elif which == "nfm4":  # four single-group NFM channels at config 3's rate: two lane pairs of equal tap-row group
+    fs, secs, uniq = 20e6, 60.0, 2.0
+    targets = [(25e3, "nfm", 12500.0), (-1.3e6, "nfm", 12500.0), (2.3e6, "nfm", 12500.0), (-3.3e6, "nfm", 12500.0)]
 else:
     fs, secs, uniq = 50e6, float(os.environ.get("SECS", "24")), 1.0  # 24 s = 4.8 GB of the 120 s capture
     targets = [(-1.95e6 + 100e3 * k, "nfm", 12500.0) for k in (0, 1, 19, 20, 39)]
 n_total = int(fs * secs)
-host = synthetic_multi_iq_s16(fs, uniq, [(o, 0.14 if which == "c3" else 0.02, m) for o, m, _ in targets]).reshape(-1)
+host = synthetic_multi_iq_s16(fs, uniq, [(o, 0.14 if which in ("c3", "nfm4") else 0.02, m) for o, m, _ in targets]).reshape(-1)
 d, fs_ch = P.choose_decimation(fs, 96000.0)
 slack = max(ResidentCaptureRunner.padded_capture_frames(d, 32769)[1], 8192)
 buf = torch.zeros(2 * (n_total + slack), dtype=torch.int16, device="cuda")
