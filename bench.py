@@ -211,7 +211,8 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
                     f"({'/'.join(str(t) for t in taps)} taps = {launch['lanes'] if launch else '?'} tap-row-group lanes), AGC on, D={d}",
         "value": round(n / dt / 1e6, 1), "unit": "MS/s of capture", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
         "channel_samples_per_s": round(len(C3_TARGETS) * n / dt / 1e9, 2),
-        "roofline": {"bound": "mfma", "kernel": ts[-1]["kernel"] + "_multi", "launch": launch, "kernel_ms": round(chan_ms, 4),
+        "roofline": {"bound": "mfma", "kernel": ts[-1]["kernel"] + ("_pairs" if launch and launch.get("pairs") else "_multi"), "launch": launch,
+                     "kernel_ms": round(chan_ms, 4),
                      "note": "kernel_ms = the one multi-lane channelizer pass (+ its combine launches) per capture, by events; "
                              "achieved = algorithmic int8 ops (3 int8 MACs per 16x16-bit tap x sample MAC) / kernel time; peak = dense "
                              "int8 MFMA (2 x the 2.5 PFLOP/s bf16 figure of MI355X_MICROARCH.md)",
@@ -219,7 +220,7 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
                      "frac": round(int8_ops / (chan_ms * 1e-3) / 1e12 / 5000.0, 5), "algorithmic_int8_ops_per_launch": int8_ops,
                      "hbm": {"algorithmic_bytes_per_launch": algo, "achieved_gb_per_s": round(algo / (chan_ms * 1e-3) / 1e9, 2),
                              "frac_of_8_tb_per_s": round(algo / (chan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                             "traffic_over_algorithmic": 1.15, "traffic_source": "profiles/r02_bank_pmc_summary.json (separate rocprofv3 "
+                             "traffic_over_algorithmic": 1.17, "traffic_source": "profiles/r02c_bank_pmc_summary.json (separate rocprofv3 "
                                                                                  "--pmc passes of profiles/bench_bank.py; NOT measured in this run)"}},
         "parity": {"bar": 1e-4, "per_target": parity},
     }

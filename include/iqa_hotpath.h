@@ -22,8 +22,11 @@
  *     lives in small caller-owned device buffers whose layouts are given below, so
  *     the library keeps no per-stream or per-capture state and is re-entrant per stream and
  *     per host thread.  What it does keep, process-wide and thread-safe: one bit per
- *     (kernel, device id) "dynamic-LDS limit raised" (atomics), and the spectrum entry point's
- *     LRU of rocFFT plans keyed by (device, nfft, batch) behind a mutex.
+ *     (kernel, device id) "dynamic-LDS limit raised" (atomics), the spectrum entry point's
+ *     LRU of rocFFT plans keyed by (device, nfft, batch) behind a mutex, and 64 KiB of pacing
+ *     words per device for iqa_channelize_mfma_pairs (the ONE exception to "never allocate":
+ *     hipMalloc + hipMemset at the first pair launch on a device -- make that call outside a
+ *     stream capture; entries are tagged per launch, nothing is reset afterwards).
  */
 #ifndef IQA_HOTPATH_H
 #define IQA_HOTPATH_H

@@ -56,7 +56,7 @@ for k in set(fetch) | set(write):
     traffic[k] = {"launches_profiled": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KiB_median": f, "WRITE_SIZE_KiB_median": w,
                   "read_bytes_per_launch": (2.0 if wide else 1.0) * f * 1024.0, "written_bytes_per_launch": w * 1024.0}
 summary["hbm_traffic"] = traffic
-ring = next((v for k, v in traffic.items() if "ring_multi" in k), None)
+ring = next((v for k, v in traffic.items() if "ring_multi" in k or "ring_pairs" in k), None)
 comb = next((v for k, v in traffic.items() if "combine" in k), None)
 n, targets = 1.2e9, 5
 algo = 4.0 * n + targets * 4.0 * 48000.0 / 20e6 * n
@@ -74,11 +74,11 @@ if ring:
 for p in ("p1", "p2", "p3"):
     c = counters(p)
     for k, v in c.items():
-        if "ring_multi" in k:
+        if "ring_multi" in k or "ring_pairs" in k:
             summary.setdefault("ring_multi_counters_median", {}).update({name: med(vals) for name, vals in v.items()})
 cm = summary.get("ring_multi_counters_median", {})
 if cm.get("GRBM_GUI_ACTIVE") and summary.get("kernel_stats"):
-    ms = next(v["avg_ms"] for k, v in summary["kernel_stats"].items() if "ring_multi" in k)
+    ms = next(v["avg_ms"] for k, v in summary["kernel_stats"].items() if "ring_multi" in k or "ring_pairs" in k)
     cyc = cm["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
     summary["derived"] = {"kernel_cycles": cyc, "note": "GRBM_GUI_ACTIVE / 8; clock = cycles / the profiled pass's own duration (not kept): ~1.9 GHz",
                           "mfma_busy_of_all_simd_cycles": cm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024.0),
