@@ -66,7 +66,9 @@
 #define IQA_RING_STAGGER 0
 #endif
 #ifndef IQA_RING_PAIR_ROUNDS
-#define IQA_RING_PAIR_ROUNDS 5  // ring depth of the lane-pair kernel in rounds (2..5)
+#define IQA_RING_PAIR_ROUNDS 3  // ring depth of the lane-pair kernel in rounds (2..5).  Its speed does not depend on it (2, 3, 5:
+                                // 9.19 / 9.08 / 9.08 ms at config 3); at 3 a workgroup leaves 59 KB of a CU's LDS to the small
+                                // kernels of the previous capture's tail (the resampler wants 20), at 5 only 3
 #endif
 
 #include <atomic>

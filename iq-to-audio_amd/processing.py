@@ -568,15 +568,18 @@ class ChannelBank:
             return False
         return len({k._ring_mode for k in ks}) == 1
 
-    def process(self, raw, outs=None, last_block: bool = False, halo=None) -> list:
-        """One block of the capture for every channel; returns the decimated streams in channel order."""
+    def process(self, raw, outs=None, last_block: bool = False, halo=None, edge_stream=None) -> list:
+        """One block of the capture for every channel; returns the decimated streams in channel order.
+        ``edge_stream``: optional torch stream for the small float32 launches of every channel's first and last outputs
+        (they write their own part of the outputs); the caller orders it against the producers of ``raw`` and the
+        consumers of the outputs, as with ``Channelizer.process``."""
         x, n = _as_frames(raw, self.fmt)
         outs = list(outs) if outs is not None else [None] * len(self.chans)
         first = self.chans[0]
         m_first, n_out = first.outputs_for(n)
         zs = None
         if n and n_out and D.is_tensor(raw) and self._shared_shape():
-            zs = self._run_shared(x, n, m_first, n_out, outs, halo)
+            zs = self._run_shared(x, n, m_first, n_out, outs, halo, edge_stream)
         if zs is None:
             self.last_launch = None
             return [c.process(raw, out_dev=o, last_block=last_block, halo=halo) for c, o in zip(self.chans, outs)]
@@ -619,7 +622,7 @@ class ChannelBank:
         self.last_launch = dict(lanes=len(kernels), launches=1, combines=0)
         return True
 
-    def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo):
+    def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo, edge_stream=None):
         kernels = [c._kernel for c in self.chans]
         consumed = self.chans[0].consumed
         big, big_frames, big_consumed = x, n, consumed
@@ -636,8 +639,8 @@ class ChannelBank:
             return None
         zs = [o if o is not None else D.empty(n_out, "complex64") for o in outs]
         for c, k, z in zip(self.chans, kernels, zs):  # each channel's own edges (history in front, end of block behind)
-            k._valu(x, n, consumed, c._hist, m_first, m_a - m_first, z)
-            k._valu(x, n, consumed, c._hist, m_b, m_first + n_out - m_b, z[m_b - m_first :])
+            k._edges(edge_stream, x, n, consumed, c._hist, m_first, m_a - m_first, z)
+            k._edges(edge_stream, x, n, consumed, c._hist, m_b, m_first + n_out - m_b, z[m_b - m_first :])
             k.last_kernel = ("k_channelize_mfma_u8" if self.fmt == "u8" else "k_channelize_mfma_s16") + "_ring"
         kranges = [(ps.k_first, ps.k_count) for ps in plans[0].passes if ps.group == 0]
         ids = [(ci, gi) for ci, mp in enumerate(plans) for gi in range(len(mp.groups))]  # lane identities
