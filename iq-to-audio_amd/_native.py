@@ -12,8 +12,11 @@ import subprocess
 from ctypes import c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
 from pathlib import Path
 
+import os
+
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libiqa_hotpath.so"
+# (IQA_LIB: an experiment build of the same library -- profiles/ use it for A/B runs of build knobs)
+LIB_PATH = Path(os.environ["IQA_LIB"]).resolve() if os.environ.get("IQA_LIB") else PKG_DIR / "libiqa_hotpath.so"
 CSRC_DIR = PKG_DIR / "csrc"
 
 IQA_OK, IQA_EINVAL, IQA_EHIP, IQA_ESTATE = 0, 1, 2, 3

@@ -38,7 +38,9 @@ class ResidentCaptureRunner:
     with the right sign before returning.  Nothing is cached between captures except the plans.
     """
 
-    SLOTS = 2
+    #: submit(resident=True): demodulator + resampler of capture i on their own stream, beside the channelizer of capture i + 1
+    tail_beside_next = bool(int(__import__("os").environ.get("IQA_TAIL_STREAM", "0")))
+    SLOTS = 3 if tail_beside_next else 2
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
@@ -109,14 +111,31 @@ class ResidentCaptureRunner:
         if resident:
             aux_done = torch.cuda.Event()
             aux_done.record(self.aux)
-            self.compute.wait_event(aux_done)  # start-up outputs and decoder state are in place (long ago)
+            if self.tail_beside_next:
+                self.__dict__.setdefault("_tail", torch.cuda.Stream()).wait_event(aux_done)
+            else:
+                self.compute.wait_event(aux_done)  # start-up outputs and decoder state are in place (long ago)
         if probe is not None:
             probe._done = [aux_done] if resident else [gate]
-        dem.process(slot["z"], self.starts, slot["audio"])
-        pcm = self.rs.process(slot["audio"], want="pcm16")  # the float32 48 kHz stream is never stored
+        tail_done = None
+        if resident and self.tail_beside_next:
+            # demodulator + resampler on a stream of their own: they run beside the NEXT capture's channelizer (whose
+            # workgroups leave them LDS and registers on every CU, see IQA_RING_ROUNDS_MAX) instead of in front of it
+            tail = self.__dict__.setdefault("_tail", torch.cuda.Stream())
+            tail.wait_event(ring_done)
+            with D.on_stream(tail, self.compute):
+                dem.process(slot["z"], self.starts, slot["audio"])
+                pcm = self.rs.process(slot["audio"], want="pcm16")
+                for t_ in (slot["z"], slot["audio"], pcm):
+                    t_.record_stream(tail)
+                tail_done = torch.cuda.Event()
+                tail_done.record(tail)
+        else:
+            dem.process(slot["z"], self.starts, slot["audio"])
+            pcm = self.rs.process(slot["audio"], want="pcm16")  # the float32 48 kHz stream is never stored
         done = torch.cuda.Event()
         # tail_done: recorded lazily (tail_event) -- the next capture's gate lies behind it anyway
-        ticket = dict(chan=chan, dem=dem, pcm=pcm, done=done, tail_done=None, kernel=chan._kernel.last_kernel,
+        ticket = dict(chan=chan, dem=dem, pcm=pcm, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel,
                       slot=slot, egress_queued=False, resident=resident)
         self._egress_pending = ticket
         return ticket
@@ -141,6 +160,8 @@ class ResidentCaptureRunner:
         torch = D.torch_mod()
         if gate is not None:
             self.egress.wait_event(gate)  # (behind the capture's last kernel too: same stream, recorded later)
+            if t.get("tail_done") is not None:
+                self.egress.wait_event(t["tail_done"])  # (its tail ran on a stream of its own)
         else:
             self.egress.wait_event(self.tail_event(t))
         # (called with the compute stream current: from submit/_chain and from collect)

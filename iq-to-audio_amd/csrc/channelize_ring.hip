@@ -65,6 +65,9 @@
 #ifndef IQA_RING_STAGGER
 #define IQA_RING_STAGGER 0
 #endif
+#ifndef IQA_RING_ROUNDS_MAX
+#define IQA_RING_ROUNDS_MAX 5  // ring depth of the single-lane kernels in rounds of two tiles, where LDS allows it
+#endif
 #ifndef IQA_RING_PAIR_ROUNDS
 #define IQA_RING_PAIR_ROUNDS 3  // ring depth of the lane-pair kernel in rounds (2..5).  Its speed does not depend on it (2, 3, 5:
                                 // 9.19 / 9.08 / 9.08 ms at config 3); at 3 a workgroup leaves 59 KB of a CU's LDS to the small
@@ -140,7 +143,7 @@ struct RingGeo {
     static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
     static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
-    static constexpr int RCAP = PAIR ? IQA_RING_PAIR_ROUNDS : 5;
+    static constexpr int RCAP = PAIR ? IQA_RING_PAIR_ROUNDS : IQA_RING_ROUNDS_MAX;
     static constexpr int R = R0 > RCAP ? RCAP : (R0 < 2 ? 2 : R0);  // rounds (of two tiles; PAIR: of one) the ring holds
     static constexpr int THREADS = (RG_WAVES + (LOADERS ? 2 : 0)) * kWave;
     static constexpr int LDS_BYTES = R * TPR * SLOT + ACCS * RG_ACC_BYTES;
