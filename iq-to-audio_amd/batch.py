@@ -383,8 +383,10 @@ class ResidentBankRunner:
             arrived = torch.cuda.Event()
             arrived.record(main)
             side.wait_event(arrived)
-        # (the probes stay on the caller's stream: they are ring-kernel launches that want most of a CU's LDS and would sit
-        # behind the running pass until it ends, one per pass boundary)
+        # (the probes stay on the caller's stream: as ring-kernel launches they want most of a CU's LDS and would sit behind
+        # the running pass until it ends, one per pass boundary; through the float32 kernel -- MixSignProbe(matrix_cores=
+        # False) -- they fit beside it but the long filters' probes then take longer than the pass has room for: 10.4
+        # against 9.4 ms per capture at config 3)
         probes = [None if s["mix_sign"] in (1, -1) else
                   MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order)
                   for s in self.targets]

@@ -703,6 +703,26 @@ class ChannelBank:
                 part = ids[lo : lo + self.MAX_LANES]
                 launch(part, "iqa_channelize_mfma_multi", len(part))
         combines = 0
+        torch = D.torch_mod()
+        main = torch.cuda.current_stream()
+        if edge_stream is not None and any(len(mp.groups) > 1 for mp in plans):
+            # the combine launches go where the consumers of the outputs are queued (behind the pass): the caller's stream
+            # then holds the pass alone
+            passed = torch.cuda.Event()
+            passed.record(main)
+            edge_stream.wait_event(passed)
+            for t in partial.values():
+                t.record_stream(edge_stream)
+            torch.cuda.set_stream(edge_stream)
+        try:
+            combines = self._combine(plans, kernels, partial, raw, m_a, m_first, n_int, zs)
+        finally:
+            torch.cuda.set_stream(main)
+        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines, pairs=n_pairs)
+        return zs
+
+    def _combine(self, plans, kernels, partial, raw, m_a, m_first, n_int, zs) -> int:
+        combines = 0
         for ci, mp in enumerate(plans):
             if len(mp.groups) > 1:
                 ptrs = (c_void_p * len(mp.groups))(*[partial[(ci, gi)].data_ptr() for gi in range(len(mp.groups))])
@@ -716,8 +736,7 @@ class ChannelBank:
                 N.call("iqa_mfma_combine", byref(kernels[ci].params), ptrs, c_int32(len(mp.groups)), scale, c_int64(m_a),
                        c_int64(n_int), N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
                 combines += 1
-        self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines, pairs=n_pairs)
-        return zs
+        return combines
 
 
 def _mean_power_into(z_dev, skip: int, out_slot) -> None:
@@ -756,9 +775,12 @@ class MixSignProbe:
     DIRECT_MAX = 65536
 
     def __init__(self, warmup, sample_rate: float, freq_offset: float, taps: np.ndarray, decimation: int, *,
-                 fmt: str = "f32", iq_order: str = "iq", record_done: bool = True):
+                 fmt: str = "f32", iq_order: str = "iq", record_done: bool = True, matrix_cores: bool = True):
         """``record_done=False``: the caller sets ``_done`` to event(s) of its own that lie behind both probes (an
-        event record between two kernels of a stream costs ~7 us on this part)."""
+        event record between two kernels of a stream costs ~7 us on this part).  ``matrix_cores=False``: the probes go
+        through the float32 kernel (a few thousand outputs: tens of microseconds), which -- unlike a ring-kernel launch
+        -- finds room on a CU beside a running channelizer pass."""
+        self._matrix_cores = bool(matrix_cores)
         self._powers = None
         self.power = None
         self._valid = [False, False]
@@ -775,7 +797,7 @@ class MixSignProbe:
         self._powers = D.empty(2, "float64")  # iqa_mean_power overwrites its slot
         self._host = _pinned_scalars(id(self))
         self._sign = None
-        if not self._probe_pair(x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order):
+        if not (self._matrix_cores and self._probe_pair(x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)):
             for i, sign in enumerate((1, -1)):
                 self._probe_one(i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)
         self._done = None
@@ -818,7 +840,7 @@ class MixSignProbe:
         # initial state nor anything past the snippet: when the warm-up buffer is longer than the snippet they are
         # all interior outputs of the matrix-core kernel -- one launch per sign instead of three.
         z_keep = D.empty(n_z - discard, "complex64")
-        if fmt in ("s16", "u8") and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
+        if self._matrix_cores and fmt in ("s16", "u8") and ch._kernel.run_interior_only(x_all, n_in, discard, n_z - discard, z_keep):
             # a short reduction is one block that WRITES its result: straight into the mapped pinned slot, no
             # device scalar and no copy behind it (a blit between kernels costs ~13 us of a 0.9 ms capture)
             direct = z_keep.numel() <= self.DIRECT_MAX
@@ -832,9 +854,11 @@ class MixSignProbe:
             discard = min(ntaps, z.numel() // 4)
             if z.numel() - discard == 0:
                 discard = 0
-            _mean_power_into(z, discard, self._powers[i : i + 1])
+            direct = z.numel() - discard <= self.DIRECT_MAX  # (one workgroup writes the mean: straight into the pinned slot)
+            _mean_power_into(z, discard, (self._host if direct else self._powers)[i : i + 1])
             self._valid[i] = True
-            self._host[i : i + 1].copy_(self._powers[i : i + 1], non_blocking=True)
+            if not direct:
+                self._host[i : i + 1].copy_(self._powers[i : i + 1], non_blocking=True)
 
     def result(self) -> int:
         if self._powers is None:
