@@ -143,7 +143,7 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
                     f"bw 12.5 kHz, D={d}, {len(taps)} taps",
         "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
         "step": "captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured)",
-        "ms_per_step_direct_launches": round(dt_eager * 1e3, 4),
+        "ms_per_step_direct_launches": round(dt_eager * 1e3, 4), "replays_redone_for_sign": int(getattr(runner, "replays_redone", 0)),
         "roofline": {"kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                      "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},

@@ -14,7 +14,7 @@ import numpy as np
 from . import _dev as D
 from . import _native as N
 from . import dsp_plan as P
-from .processing import ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps
+from .processing import ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps, probe_targets
 
 
 class ResidentCaptureRunner:
@@ -287,6 +287,7 @@ class ResidentCaptureRunner:
             ticket["done"].synchronize()
             sign = ticket["graph_probe"].peek()
             if sign != ticket["sign"]:  # the captured step assumed +1: this capture again, the ordinary way
+                self.replays_redone = getattr(self, "replays_redone", 0) + 1
                 redo = self._chain(ticket["raw"], slot, sign, None, ticket.get("halo"), False)
                 self._flush_egress()
                 ticket.update(redo, sign=sign, probe=None, raw=ticket["raw"], graph_probe=None)
@@ -354,7 +355,7 @@ class ResidentBankRunner:
                         pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(),
                         dem=ChannelDemod(s["demod_mode"], self.fs_ch, deemph_us=s["deemph_us"], agc_enabled=s["agc_enabled"]))
                    for s in self.targets]
-            self.slots.append(dict(per=per, busy=None))
+            self.slots.append(dict(per=per, busy=None, probe_host=torch.empty(2 * len(self.targets), dtype=torch.float64).pin_memory()))
         self._next = 0
 
     def _channelizer(self, spec, sign: int) -> Channelizer:
@@ -387,9 +388,17 @@ class ResidentBankRunner:
         # the running pass until it ends, one per pass boundary; through the float32 kernel -- MixSignProbe(matrix_cores=
         # False) -- they fit beside it but the long filters' probes then take longer than the pass has room for: 10.4
         # against 9.4 ms per capture at config 3)
-        probes = [None if s["mix_sign"] in (1, -1) else
-                  MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order)
-                  for s in self.targets]
+        todo = [i for i, s in enumerate(self.targets) if s["mix_sign"] not in (1, -1)]
+        grouped = probe_targets(warm, self.fs, [(self.targets[i]["freq_offset"], self.targets[i]["taps"]) for i in todo], self.d,
+                                fmt=self.fmt, iq_order=self.iq_order, host=slot["probe_host"]) if len(todo) > 1 else None
+        if grouped is not None:  # every target's two probes as channels of one bank over the snippet
+            probes = [None] * len(self.targets)
+            for i, pr in zip(todo, grouped):
+                probes[i] = pr
+        else:
+            probes = [None if s["mix_sign"] in (1, -1) else
+                      MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order)
+                      for s in self.targets]
         signs = [s["mix_sign"] if s["mix_sign"] in (1, -1) else 1 for s in self.targets]
         chans = [self._channelizer(s, sg) for s, sg in zip(self.targets, signs)]
         for c in chans:

@@ -588,16 +588,21 @@ class ChannelBank:
         return zs
 
     def run_interior_only(self, x_all, n_frames: int, m_first: int, n_out: int, outs: list) -> bool:
-        """Outputs [m_first, m_first + n_out) of a block that starts the capture, for every channel, in ONE launch and
-        matrix-core kernels only (no edges): what ``_ChannelKernel.run_interior_only`` does for one channel.  For
-        single-group, single-pass filters; False (nothing launched) otherwise."""
-        kernels = [c._kernel for c in self.chans]
-        if len(kernels) > self.MAX_LANES or n_out < 64 or not self._shared_shape():
+        """Outputs [m_first, m_first + n_out) of a block that starts the capture, for every channel, matrix-core kernels
+        only (no float32 edge launches): what ``_ChannelKernel.run_interior_only`` does for one channel, for callers that
+        do not want the outputs near the block's edges (the mixer-sign probes).  False (nothing launched) when the range
+        is not interior for every channel or the channels do not share a kernel shape."""
+        if n_out < 64 or not self._shared_shape():
             return False
+        kernels = [c._kernel for c in self.chans]
+        plans = [k._ensure_mfma() for k in kernels]
+        if len(kernels) > self.MAX_LANES or any(len(mp.groups) != 1 or len(mp.passes) != 1 for mp in plans):
+            # filters with several tap-row groups / k-step passes: partial sums and combine launches as for a whole block
+            return self._run_shared(x_all, n_frames, m_first, n_out, list(outs), None, None, interior_only=True) is not None
+        # single-group, single-pass filters (the usual probe): one lane each, one launch, nothing else
         if any(k._interior(0, n_frames, m_first, n_out) != (m_first, m_first + n_out) for k in kernels):
             return False
-        plans = [k._ensure_mfma() for k in kernels]
-        if any(len(mp.groups) != 1 or len(mp.passes) != 1 for mp in plans) or len({(mp.passes[0].k_first, mp.passes[0].k_count) for mp in plans}) != 1:
+        if len({(mp.passes[0].k_first, mp.passes[0].k_count) for mp in plans}) != 1:
             return False
         ps0 = plans[0].passes[0]
         ranges = 8 * max(1, (_ChannelKernel.launch_blocks // 8) // len(kernels))
@@ -619,10 +624,10 @@ class ChannelBank:
         N.call("iqa_channelize_mfma_multi", c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(ps0.k_first),
                c_int32(ps0.k_count), c_int32(rng), table, c_int32(len(kernels)), N.ptr(x_all), c_int64(n_frames), c_int64(0),
                c_int64(m_first), c_int64(n_out), N.stream_ptr())
-        self.last_launch = dict(lanes=len(kernels), launches=1, combines=0)
+        self.last_launch = dict(lanes=len(kernels), launches=1, combines=0, pairs=0)
         return True
 
-    def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo, edge_stream=None):
+    def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo, edge_stream=None, interior_only: bool = False):
         kernels = [c._kernel for c in self.chans]
         consumed = self.chans[0].consumed
         big, big_frames, big_consumed = x, n, consumed
@@ -631,7 +636,10 @@ class ChannelBank:
             big_frames, big_consumed = int(big.numel()) // 2, consumed - int(lead)
         spans = [k._interior(big_consumed, big_frames, m_first, n_out) for k in kernels]
         m_a, m_b = max(s[0] for s in spans), min(s[1] for s in spans)
-        if any(s[1] <= s[0] for s in spans) or m_b - m_a < _ChannelKernel.mfma_min_outputs:
+        if interior_only:
+            if any(s != (m_first, m_first + n_out) for s in spans):
+                return None
+        elif any(s[1] <= s[0] for s in spans) or m_b - m_a < _ChannelKernel.mfma_min_outputs:
             return None
         n_int = m_b - m_a
         plans = [k._ensure_mfma() for k in kernels]
@@ -639,8 +647,9 @@ class ChannelBank:
             return None
         zs = [o if o is not None else D.empty(n_out, "complex64") for o in outs]
         for c, k, z in zip(self.chans, kernels, zs):  # each channel's own edges (history in front, end of block behind)
-            k._edges(edge_stream, x, n, consumed, c._hist, m_first, m_a - m_first, z)
-            k._edges(edge_stream, x, n, consumed, c._hist, m_b, m_first + n_out - m_b, z[m_b - m_first :])
+            if not interior_only:
+                k._edges(edge_stream, x, n, consumed, c._hist, m_first, m_a - m_first, z)
+                k._edges(edge_stream, x, n, consumed, c._hist, m_b, m_first + n_out - m_b, z[m_b - m_first :])
             k.last_kernel = ("k_channelize_mfma_u8" if self.fmt == "u8" else "k_channelize_mfma_s16") + "_ring"
         kranges = [(ps.k_first, ps.k_count) for ps in plans[0].passes if ps.group == 0]
         ids = [(ci, gi) for ci, mp in enumerate(plans) for gi in range(len(mp.groups))]  # lane identities
@@ -702,12 +711,13 @@ class ChannelBank:
             for lo in range(0, len(ids), self.MAX_LANES):
                 part = ids[lo : lo + self.MAX_LANES]
                 launch(part, "iqa_channelize_mfma_multi", len(part))
-        combines = 0
-        torch = D.torch_mod()
-        main = torch.cuda.current_stream()
+        main = None
         if edge_stream is not None and any(len(mp.groups) > 1 for mp in plans):
             # the combine launches go where the consumers of the outputs are queued (behind the pass): the caller's stream
-            # then holds the pass alone
+            # then holds the pass alone.  (No stream calls at all otherwise: this function also runs inside graph captures,
+            # where a set_stream -- even to the current stream -- made the replays 2.5x slower.)
+            torch = D.torch_mod()
+            main = torch.cuda.current_stream()
             passed = torch.cuda.Event()
             passed.record(main)
             edge_stream.wait_event(passed)
@@ -717,7 +727,8 @@ class ChannelBank:
         try:
             combines = self._combine(plans, kernels, partial, raw, m_a, m_first, n_int, zs)
         finally:
-            torch.cuda.set_stream(main)
+            if main is not None:
+                D.torch_mod().cuda.set_stream(main)
         self.last_launch = dict(lanes=len(ids), launches=launches, combines=combines, pairs=n_pairs)
         return zs
 
@@ -737,6 +748,43 @@ class ChannelBank:
                        c_int64(n_int), N.ptr(zs[ci][m_a - m_first :]), N.stream_ptr())
                 combines += 1
         return combines
+
+
+def probe_targets(warmup, sample_rate: float, specs: list, decimation: int, *, fmt: str, iq_order: str, host) -> list | None:
+    """The mixer-sign probes of SEVERAL targets of one capture (``specs``: ``(freq_offset, taps)`` each) in as few launches
+    as one bank takes: both signs of every target are channels of one :class:`ChannelBank` over the snippet (lane pairs,
+    tap-row groups and their combine launches as for the capture itself) and ONE reduction writes all mean powers into
+    ``host`` (pinned float64, two per target, owned by the caller until the probes have been read).  Returns one
+    :class:`MixSignProbe` per target, or None when the grouped path does not apply (the caller then probes target by
+    target): float32 captures, targets whose snippet or discard lengths differ, kernels without a shared shape."""
+    if fmt not in ("s16", "u8") or not specs:
+        return None
+    x_all, n_in = _as_frames(warmup, fmt)
+    decim = max(decimation, 1)
+    shapes = set()
+    for _, taps in specs:  # the lengths MixSignProbe.__init__ / _probe_one derive (reference processing.py:636-656)
+        ntaps = len(taps)
+        snippet = min(n_in, max(int(sample_rate * 0.05), ntaps * 4, 131_072))
+        if snippet < ntaps:
+            snippet = min(n_in, ntaps * 2)
+        n_z = -(-snippet // decim)
+        discard = min(ntaps, n_z // 4)
+        shapes.add((n_z, discard if n_z - discard else 0))
+    if len(shapes) != 1:
+        return None
+    n_z, discard = shapes.pop()
+    keep = n_z - discard
+    if keep < 64 or keep > MixSignProbe.DIRECT_MAX or host.numel() < 2 * len(specs):
+        return None
+    chans = [Channelizer(taps, sample_rate=sample_rate, freq_offset=f_off, mix_sign=sign, decimation=decim, fmt=fmt, iq_order=iq_order)
+             for f_off, taps in specs for sign in (1, -1)]
+    z_keep = D.empty(len(chans) * keep, "complex64")
+    if not ChannelBank(chans).run_interior_only(x_all, n_in, discard, keep, [z_keep[i * keep : (i + 1) * keep] for i in range(len(chans))]):
+        return None
+    N.call("iqa_mean_power_batch", N.ptr(z_keep), c_int64(keep), c_int32(len(chans)), c_int64(0), N.ptr(host), N.stream_ptr())
+    done = D.torch_mod().cuda.Event()
+    done.record()
+    return [MixSignProbe.from_powers(host[2 * i : 2 * i + 2], done) for i in range(len(specs))]
 
 
 def _mean_power_into(z_dev, skip: int, out_slot) -> None:
@@ -804,6 +852,15 @@ class MixSignProbe:
         if record_done:
             self._done = D.torch_mod().cuda.Event()
             self._done.record()
+
+    @classmethod
+    def from_powers(cls, host_pair, done_event):
+        """A probe whose two mean powers (sign +1, sign -1) are being written into ``host_pair`` (a pinned float64[2] the
+        caller owns) by launches already queued; ``done_event`` lies behind them.  See ``probe_targets``."""
+        self = cls.__new__(cls)
+        self._powers, self.power, self._valid, self._sign = host_pair, None, [True, True], None
+        self._host, self._done, self._matrix_cores = host_pair, done_event, True
+        return self
 
     def _probe_pair(self, x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order) -> bool:
         """Both signs in two launches instead of four: the two channelizers as the two lanes of one matrix-core launch
