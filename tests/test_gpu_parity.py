@@ -147,6 +147,26 @@ def test_mix_sign_probes_share_a_launch(A):
             powers.append(float(np.mean(np.abs(zz).astype(np.float32).astype(np.float64) ** 2)))
         assert sign == side == (1 if powers[0] >= powers[1] else -1)
         assert abs(pair.power - max(powers)) <= 1e-6 * max(powers)
+    # several targets at once (processing.probe_targets: both signs of every target as channels of ONE bank over the
+    # snippet -- tap-row groups, lane pairs and combine launches included) against one MixSignProbe per target
+    import torch
+
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+    from iq_to_audio_amd.processing import probe_targets
+
+    fs3, d3 = 20e6, 208
+    carriers = [(25e3, 0.2, "nfm"), (-150e3, 0.2, "am"), (400e3, 0.2, "usb"), (-1.1e6, 0.2, "nfm")]
+    cap = D.to_device(synthetic_multi_iq_s16(fs3, 0.12, carriers, seed=5).reshape(-1), "int16")
+    specs = [(25e3, A.design_channel_filter(fs3, 12_500.0, d3)), (-150e3, A.design_channel_filter(fs3, 10_000.0, d3)),
+             (400e3, A.design_channel_filter(fs3, 2_800.0, d3)), (1.1e6, A.design_channel_filter(fs3, 12_500.0, d3))]  # last one: mirrored
+    host_slots = torch.empty(2 * len(specs), dtype=torch.float64).pin_memory()
+    grouped = probe_targets(cap, fs3, specs, d3, fmt="s16", iq_order="iq", host=host_slots)
+    assert grouped is not None and len(grouped) == len(specs)
+    for (f_off3, taps3), pr in zip(specs, grouped):
+        one = MixSignProbe(cap, fs3, f_off3, taps3, d3, fmt="s16")
+        assert pr.result() == one.result()
+        assert abs(pr.power - one.power) <= 1e-6 * one.power
+    assert [pr.result() for pr in grouped] == [1, 1, 1, -1]
     # the batched reduction against numpy, short (one workgroup per part, written) and long (accumulated) parts
     rng = np.random.default_rng(11)
     for n_each, parts, skip in ((1000, 3, 7), (70_000, 2, 0)):
