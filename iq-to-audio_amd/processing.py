@@ -518,10 +518,30 @@ class Channelizer:
         m_first, n_out = self.outputs_for(n)
         if halo is not None and (self.fmt not in ("s16", "u8") or not D.is_tensor(raw)):
             halo = None
-        z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo, edge_stream)
-             if n_out else D.empty(0, "complex64"))
+        z = None
+        if n_out and D.is_tensor(raw) and self._several_lanes():
+            # a filter with several tap-row groups: its groups as lanes of ONE shared-ingest launch (in pairs where the
+            # kernel offers them) + the combine launch, instead of one pass over the capture per group
+            if events:
+                events[0].record()
+            zs = ChannelBank([self])._run_shared(x, n, m_first, n_out, [out_dev], halo, edge_stream)
+            if zs is not None:
+                z = zs[0]
+                if events:
+                    events[1].record()
+        if z is None:
+            z = (self._kernel.run(x, n, self.consumed, self._hist, m_first, n_out, out_dev, events, halo, edge_stream)
+                 if n_out else D.empty(0, "complex64"))
         self._advance(x, n, last_block)
         return D.like_input(z, raw)
+
+    def _several_lanes(self) -> bool:
+        k = self._kernel
+        if not (self.lanes_for_groups and self.fmt in ("s16", "u8") and k._mfma_ok and k.mfma_variant == "ring" and k._ring_mode and k.ring_acc32):
+            return False
+        return len(k._ensure_mfma().groups) > 1
+
+    lanes_for_groups = True  # (class switch: profiles compare against the chained passes)
 
     def _advance(self, x, n: int, last_block: bool = False) -> None:
         """Carry the last L-1 raw frames over to the next block and move on by ``n`` frames."""
@@ -564,8 +584,10 @@ class ChannelBank:
 
     def _shared_shape(self) -> bool:
         ks = [c._kernel for c in self.chans]
-        if len(ks) < 2 or not all(k._mfma_ok and k.mfma_variant == "ring" and k._ring_mode and k.ring_acc32 for k in ks):
+        if not ks or not all(k._mfma_ok and k.mfma_variant == "ring" and k._ring_mode and k.ring_acc32 for k in ks):
             return False
+        if len(ks) == 1:  # one channel: worth a shared-ingest launch only when its filter is several lanes (tap-row groups)
+            return len(ks[0]._ensure_mfma().groups) > 1
         return len({k._ring_mode for k in ks}) == 1
 
     def process(self, raw, outs=None, last_block: bool = False, halo=None, edge_stream=None) -> list:

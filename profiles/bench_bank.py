@@ -45,6 +45,7 @@ def run(mode):
         bank.pair_lanes = mode == "bank"
         zs = bank.process(raw, outs=outs, last_block=True, halo=(buf, 0))
         return zs, bank.last_launch
+    A.Channelizer.lanes_for_groups = mode != "chained"  # chained: a filter's tap-row groups as passes over the capture, one after the other
     return [c.process(raw, out_dev=o, last_block=True, halo=(buf, 0)) for c, o in zip(chans, outs)], None
 
 K, WARM = int(os.environ.get("K", "20")), int(os.environ.get("WARM", "5"))
