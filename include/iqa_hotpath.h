@@ -308,6 +308,13 @@ typedef struct {
 int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
                    const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev, void *audio_out_dev,
                    void *scratch_dev, void *work_dev, void *stream);
+/* The same for the FIRST block of a stream: a decoder that has seen nothing (decoder setup / AudioWriter creation in
+ * ProcessingPipeline.run, processing.py:1040-1066).  state_dev is not read (prev = 1+0j, filter states 0; it receives the
+ * outgoing state as usual), peak_dev and sumsq_dev[0 .. n_segs*IQA_SUMSQ_SLOTS) are cleared by the call itself: no
+ * reset copy in front of it (a node less in a captured step).  n > 0. */
+int iqa_demodulate_from_reset(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
+                              const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev,
+                              void *audio_out_dev, void *scratch_dev, void *work_dev, void *stream);
 
 /* ref: AudioWriter.write, processing.py:440-456: peak = max(peak, max|a|) BEFORE the clip, then
  * clip to +-0.99.  peak_dev = float[1] (running, init 0).  In-place allowed (out_dev == a_dev).

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "iqa_agc": (ctypes.c_int, [c_void_p, c_int64, c_double, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "iqa_demodulate": (ctypes.c_int, [ctypes.POINTER(DemodParams), c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "iqa_demodulate_from_reset": (ctypes.c_int, [ctypes.POINTER(DemodParams), c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iqa_writer_clip": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "iqa_resample": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64, c_void_p,
                                     c_void_p, c_void_p]),

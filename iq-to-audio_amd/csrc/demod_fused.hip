@@ -39,6 +39,8 @@ struct FusedArgs {
     double *fin;
     int nblocks;
     int z_aligned, y_aligned;  // z / y are 16-byte aligned: the vector load / store paths may be used
+    int fresh;  // the decoder has seen nothing: prev = 1 + 0j, filter states 0 (the caller's state block is not read), and the
+                // carry pass clears the peak and the per-chunk sums -- iqa_demodulate_from_reset, no reset copy in front
 };
 
 template <int SRC>
@@ -64,7 +66,7 @@ __device__ __forceinline__ void load_u(const FusedArgs &a, long long base, float
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i) u[i] = (base + i < a.n) ? a.x[base + i] : 0.f;
         if constexpr (OP == F_DC) {
-            if (base == 0) u_before = static_cast<float>(a.st[0]);
+            if (base == 0) u_before = a.fresh ? 0.f : static_cast<float>(a.st[0]);
             else if (base - 1 < a.n) u_before = a.x[base - 1];
         }
     } else {
@@ -106,13 +108,13 @@ __device__ __forceinline__ void load_u(const FusedArgs &a, long long base, float
             }
         }
         if constexpr (SRC == S_QUAD) {
-            if (base == 0) zz[1] = a.prev[0];  // z[-1]
+            if (base == 0) zz[1] = a.fresh ? make_float2(1.f, 0.f) : a.prev[0];  // z[-1]
         }
 #pragma unroll
         for (int i = 0; i < SC_ITEMS; ++i) u[i] = (base + i < a.n) ? src_value<SRC>(a, base + i, zz[i + 2], zz[i + 1]) : 0.f;
         if constexpr (OP == F_DC) {
             // DC blocker's x[n-1]: u[base-1] from z (ENV/REAL never need z[base-2]); carried state at 0
-            if (base == 0) u_before = static_cast<float>(a.st[0]);
+            if (base == 0) u_before = a.fresh ? 0.f : static_cast<float>(a.st[0]);
             else u_before = src_value<SRC>(a, base - 1, zz[1], zz[0]);
         }
     }
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fused_carry(FusedArgs a)
     __shared__ Aff s_w[FC_THREADS / kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s0;
-    if constexpr (OP == F_DEEMPH) s0 = a.st[0];
-    else if constexpr (OP == F_DC) s0 = a.st[1];
+    if constexpr (OP == F_DEEMPH) s0 = a.fresh ? 0.0 : a.st[0];
+    else if constexpr (OP == F_DC) s0 = a.fresh ? 0.0 : a.st[1];
     else s0 = 1.0;
     const int per = (a.nblocks + FC_THREADS - 1) / FC_THREADS;
     const int b0 = tid * per;
@@ -215,9 +217,14 @@ __global__ __launch_bounds__(FC_THREADS) void k_fused_carry(FusedArgs a)
     if (tid == FC_THREADS - 1) a.fin[0] = s;  // runs past the end are identity maps: the last thread holds the total
     // Snapshot of the incoming state for the apply pass (fin[1] = prev, fin[2] = st[0]): its last block hands the
     // outgoing state to the next call while its first block may not have read the incoming one yet.
+    if (a.fresh) {  // (the apply pass -- the only writer of these -- runs behind this kernel)
+        if (tid == 0 && a.peak_bits != nullptr) a.peak_bits[0] = 0u;
+        if (a.sumsq != nullptr)
+            for (long long i = tid; i < a.n_segs * IQA_SUMSQ_SLOTS; i += FC_THREADS) a.sumsq[i] = 0.0;
+    }
     if (tid == 0) {
-        if (a.prev != nullptr) reinterpret_cast<float2 *>(a.fin + 1)[0] = a.prev[0];
-        if (a.st != nullptr) a.fin[2] = a.st[0];
+        if (a.prev != nullptr) reinterpret_cast<float2 *>(a.fin + 1)[0] = a.fresh ? make_float2(1.f, 0.f) : a.prev[0];
+        if (a.st != nullptr) a.fin[2] = a.fresh ? 0.0 : a.st[0];
     }
 }
 
@@ -390,6 +397,7 @@ static int launch_fused(FusedArgs a, float2 *prev_out, double *st_out, void *wor
     FusedArgs b = a;  // the apply pass reads the incoming state from the carry pass's snapshot
     b.prev = reinterpret_cast<const float2 *>(a.fin + 1);
     b.st = a.fin + 2;
+    b.fresh = 0;
     hipLaunchKernelGGL((k_fused_apply<OP, SRC, SINK>), dim3(a.nblocks), dim3(SC_THREADS), 0, s, b, prev_out, st_out);
     return check_launch("fused demodulator");
 }
@@ -398,9 +406,9 @@ static int launch_fused(FusedArgs a, float2 *prev_out, double *st_out, void *wor
 
 using namespace iqa;
 
-extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
-                              const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev,
-                              void *audio_out_dev, void *scratch_dev, void *work_dev, void *stream)
+static int demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev, const void *seg_starts_dev,
+                      int64_t n_segs, void *peak_dev, void *sumsq_dev, void *audio_out_dev, void *scratch_dev, void *work_dev,
+                      void *stream, int fresh)
 {
     if (p == nullptr) return fail_inval("params is NULL");
     if (n < 0 || n_segs < 0) return fail_inval("negative length");
@@ -412,6 +420,7 @@ extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int6
     // state block: [0] float2 prev (8 B) | [8] double y_last | [16] double x_last, y_last
     char *st = static_cast<char *>(state_dev);
     FusedArgs a{};
+    a.fresh = fresh;
     a.z = static_cast<const float2 *>(z_dev);
     a.n = n;
     a.segs = static_cast<const long long *>(seg_starts_dev);
@@ -451,4 +460,19 @@ extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int6
     g.p1 = static_cast<double>(static_cast<float>(p->agc_decay));
     g.st = nullptr;
     return launch_fused<F_AGC, S_F32, K_CLIP>(g, nullptr, nullptr, work_dev, s);
+}
+
+extern "C" int iqa_demodulate(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
+                              const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev,
+                              void *audio_out_dev, void *scratch_dev, void *work_dev, void *stream)
+{
+    return demodulate(p, z_dev, n, state_dev, seg_starts_dev, n_segs, peak_dev, sumsq_dev, audio_out_dev, scratch_dev, work_dev, stream, 0);
+}
+
+extern "C" int iqa_demodulate_from_reset(const iqa_demod_params *p, const void *z_dev, int64_t n, void *state_dev,
+                                         const void *seg_starts_dev, int64_t n_segs, void *peak_dev, void *sumsq_dev,
+                                         void *audio_out_dev, void *scratch_dev, void *work_dev, void *stream)
+{
+    if (n == 0) return fail_inval("iqa_demodulate_from_reset needs samples (an empty block resets nothing)");
+    return demodulate(p, z_dev, n, state_dev, seg_starts_dev, n_segs, peak_dev, sumsq_dev, audio_out_dev, scratch_dev, work_dev, stream, 1);
 }

@@ -1034,6 +1034,7 @@ class ChannelDemod:
         self._blk = None  # one device block: [state 32 B | peak 4 B (+pad to 64) | sumsq n_chunks*8 f64]
         self._starts_key = None
         self._fresh = False
+        self._from_reset = False
         self._alloc_block(0)
 
     # {float2 prev = 1+0j; double y_last; double x_last, y_last} -- the states of a decoder that has seen nothing
@@ -1057,9 +1058,9 @@ class ChannelDemod:
         self.chunk_sumsq = []
         if self._fresh:
             return
-        if self._img_host is None:
-            self._img_host = D.torch_mod().from_numpy(self._img).pin_memory()
-        self._blk.copy_(self._img_host, non_blocking=True)
+        # nothing is copied: the next ``process`` starts from the initial state by itself and clears the peak and the
+        # per-chunk sums (iqa_demodulate_from_reset) -- one node less per capture in a captured step
+        self._from_reset = True
         self._fresh = True
 
     def prepare(self, n: int, chunk_starts: np.ndarray):
@@ -1092,7 +1093,9 @@ class ChannelDemod:
         _, _, starts_dev, sumsq, work, scratch = self._prepared
         self._prepared = None
         self._fresh = False
-        N.call("iqa_demodulate", byref(self.params), N.ptr(z_dev), c_int64(n), N.ptr(self.state_dev), N.ptr(starts_dev),
+        entry = "iqa_demodulate_from_reset" if self._from_reset else "iqa_demodulate"
+        self._from_reset = False
+        N.call(entry, byref(self.params), N.ptr(z_dev), c_int64(n), N.ptr(self.state_dev), N.ptr(starts_dev),
                c_int64(len(chunk_starts)), N.ptr(self.peak_dev), N.ptr(sumsq), N.ptr(out_dev), N.ptr(scratch), N.ptr(work),
                N.stream_ptr())
         counts = np.diff(np.append(chunk_starts, n))
@@ -1100,7 +1103,7 @@ class ChannelDemod:
 
     @property
     def peak(self) -> float:
-        return float(self.peak_dev.item())
+        return 0.0 if self._from_reset else float(self.peak_dev.item())  # (a reset not yet followed by a block)
 
     def chunk_rms_dbfs(self) -> list[float]:
         out = []
