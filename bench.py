@@ -135,8 +135,22 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     res = [runner.collect(t) for t in ts][-1]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # ... and two captures per graph (a batch of captures in fixed buffers: one graph launch for both)
+    pair = [(raw, buf, 0)] * runner.SLOTS
+    for _ in range(warm // runner.SLOTS):
+        for t in runner.submit_captured_batch(pair):
+            runner.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batches = -(-steps // runner.SLOTS)
+    for _ in range(batches):
+        for t in runner.submit_captured_batch(pair):
+            res_b = runner.collect(t)
+    torch.cuda.synchronize()
+    dt_batch = (time.perf_counter() - t0) / (batches * runner.SLOTS)
     want = O.run_chain(host, sample_rate=fs, freq_offset=f_off, keep_decimated=False)
     audio = res["audio"].cpu().numpy()
+    audio_b = res_b["audio"].cpu().numpy()
     algo = (4.0 + 4.0 * 48_000.0 / fs) * n
     return {
         "workload": "BASELINE config 1 (the reference's --benchmark capture): 5 s @ 2.5 MS/s int16 I/Q, 1 NFM channel, +25 kHz, "
@@ -144,6 +158,7 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
         "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
         "step": "captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured)",
         "ms_per_step_direct_launches": round(dt_eager * 1e3, 4), "replays_redone_for_sign": int(getattr(runner, "replays_redone", 0)),
+        "ms_per_step_two_captures_per_graph": round(dt_batch * 1e3, 4), "two_per_graph_audio_identical": bool(np.array_equal(audio, audio_b)),
         "roofline": {"kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                      "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},

@@ -14,7 +14,8 @@ import numpy as np
 from . import _dev as D
 from . import _native as N
 from . import dsp_plan as P
-from .processing import ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps, probe_targets
+from .processing import (ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps, probe_targets,
+                         reserve_pinned_scalars)
 
 
 class ResidentCaptureRunner:
@@ -232,7 +233,7 @@ class ResidentCaptureRunner:
         if self.override is None:
             warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
             probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order, record_done=False)
-        dem.reset()
+        dem.reset(force=True)
         dem.prepare(self.n_dec, self.starts)
         chan.process(raw_dev, out_dev=slot["z"], last_block=True, halo=halo)
         dem.process(slot["z"], self.starts, slot["audio"])
@@ -261,6 +262,7 @@ class ResidentCaptureRunner:
             # once the ordinary way, in this very slot: plans, tap uploads and the pinned probe slot exist afterwards
             self.collect(self.submit(raw_dev, enclosing=enclosing, lead_frames=lead_frames))
             torch.cuda.synchronize()
+            reserve_pinned_scalars(1)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 parts = self._captured_step(raw_dev, slot, halo)
@@ -276,6 +278,45 @@ class ResidentCaptureRunner:
                       sign=self.override or 1, raw=raw_dev, halo=halo)
         slot["busy"] = ticket
         return ticket
+
+    def submit_captured_batch(self, captures: list) -> list:
+        """``submit_captured`` for up to ``SLOTS`` captures at once -- ``captures``: ``(raw_dev, enclosing, lead_frames)`` each,
+        in fixed buffers -- as ONE graph: one host call and one graph launch (≈13 us on this part) for all of them.
+        Returns one ticket per capture."""
+        torch = D.torch_mod()
+        if D.current_raw_stream() != self._compute_raw:
+            raise RuntimeError("submit_captured_batch() must be called with the stream the runner was created on as the current stream")
+        if not 1 <= len(captures) <= self.SLOTS:
+            raise ValueError(f"a batch holds 1..{self.SLOTS} captures")
+        for slot in self.slots[: len(captures)]:
+            if slot["busy"] is not None:
+                self.collect(slot["busy"])
+        halos = [(enc, int(lead)) if enc is not None else None for _, enc, lead in captures]
+        key = ("batch",) + tuple((int(raw.data_ptr()), None if enc is None else int(enc.data_ptr()), int(lead)) for raw, enc, lead in captures)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        entry = graphs.get(key)
+        if entry is None:
+            self._next = 0
+            for raw, enc, lead in captures:  # once the ordinary way, each in its slot
+                self.collect(self.submit(raw, enclosing=enc, lead_frames=lead))
+            torch.cuda.synchronize()
+            reserve_pinned_scalars(len(captures))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                parts = [self._captured_step(raw, slot, halo) for (raw, _, _), slot, halo in zip(captures, self.slots, halos)]
+            entry = graphs[key] = dict(graph=g, parts=parts)
+        for p_ in entry["parts"]:
+            p_["dem"].chunk_sumsq = p_["dem"].chunk_sumsq[-1:]
+        entry["graph"].replay()
+        done = torch.cuda.Event()
+        done.record()
+        tickets = []
+        for (raw, _, _), slot, halo, p_ in zip(captures, self.slots, halos, entry["parts"]):
+            t = dict(chan=p_["chan"], dem=p_["dem"], pcm=p_["pcm"], done=done, tail_done=done, kernel=p_["kernel"], slot=slot,
+                     egress_queued=True, resident=False, probe=None, graph_probe=p_["probe"], sign=self.override or 1, raw=raw, halo=halo)
+            slot["busy"] = t
+            tickets.append(t)
+        return tickets
 
     def collect(self, ticket: dict) -> dict:
         """Wait for a submitted capture.  Returns {"pcm_host", "sign", "demod" (``.peak``, ``.chunk_rms_dbfs()``),

@@ -830,6 +830,16 @@ def _pinned_scalars(owner):
         return t[0]
 
 
+def reserve_pinned_scalars(count: int) -> None:
+    """Make sure ``count`` probe read-back buffers are free NOW (pinning memory is not allowed while a stream is being
+    captured: a caller about to capture ``count`` probes into a graph reserves them first)."""
+    torch = D.torch_mod()
+    with _KERNEL_CACHE_LOCK:
+        free = sum(1 for t in _PINNED_SCALARS if t[1] is None)
+        for _ in range(max(0, count - free)):
+            _PINNED_SCALARS.append([torch.empty(2, dtype=torch.float64).pin_memory(), None])
+
+
 def _release_scalars(buf) -> None:
     with _KERNEL_CACHE_LOCK:
         for t in _PINNED_SCALARS:
@@ -1052,11 +1062,11 @@ class ChannelDemod:
         self._sumsq = self._blk[64:].view(torch.float64)
         self._fresh = True
 
-    def reset(self) -> None:
+    def reset(self, force: bool = False) -> None:
         """Back to a decoder that has seen nothing (states, peak, per-chunk sums): one small H2D copy from a
         pinned image (pinned on the first reset: pin_memory() costs milliseconds)."""
         self.chunk_sumsq = []
-        if self._fresh:
+        if self._fresh and not force:  # (force: a step being captured into a graph must not depend on what ran before it)
             return
         # nothing is copied: the next ``process`` starts from the initial state by itself and clears the peak and the
         # per-chunk sums (iqa_demodulate_from_reset) -- one node less per capture in a captured step

@@ -501,6 +501,17 @@ def test_captured_step_replays_to_the_same_audio(A):
     ref48 = O.float_to_pcm16(O.resample_48k(ref.audio, ref.fs_channel))
     assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
     assert abs(r["demod"].peak - ref.audio_peak) < 1e-5 and len(r["demod"].chunk_rms_dbfs()) == len(ref.rms_dbfs)
+    # two captures per graph (submit_captured_batch): one graph launch for both, the same audio -- including the buffer
+    # whose probe says -1 (redone the ordinary way at collect)
+    bufs[0].copy_(D.to_device(caps[0].reshape(-1), "int16"))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        tickets = runner.submit_captured_batch([(x, None, 0) for x in bufs])
+        for (sign, pcm, audio), t in zip(want, tickets):
+            r = runner.collect(t)
+            assert r["sign"] == sign and np.array_equal(r["pcm_host"].numpy(), pcm) and torch.equal(r["audio"], audio), rep
+    with pytest.raises(ValueError):
+        runner.submit_captured_batch([(bufs[0], None, 0)] * (runner.SLOTS + 1))
 
 
 # ---- dynamic range: a full-scale interferer beside an empty channel and beside a weak one ----------
