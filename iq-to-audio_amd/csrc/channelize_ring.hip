@@ -117,7 +117,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 //     writes to (instruction base + 16 * lane) but fetches from any address, so the padding costs nothing but the
 //     per-lane source offsets (`ring_src_off`, computed once per workgroup);
 //   row-staged (ROWS = true): row j's k-step range of THIS pass, 64*KS bytes, at a pitch of 64*KS + 16 bytes (16 bytes
-//     of padding: rows 4 banks apart, conflict-free reads), one DMA per row with 4*KS active lanes.  Any D, and the
+//     of padding: rows 4 banks apart, conflict-free reads), filled 64 units per DMA instruction like the contiguous slots (RingGeo::NI_ROWS).  Any D, and the
 //     k-step ranges of a long row (D = 521: 33 k steps in three passes of 11) each fetch only their own third of every
 //     row, so three passes read the capture about once instead of three times.  Always with loader waves.
 // U8 (row-staged only): uint8 I/Q captures -- a k step is 32 bytes of a row, one 16-byte fragment per lane, the
@@ -137,9 +137,15 @@ struct RingGeo {
     static constexpr int PITCH = KBYTES * KS + 16;
     static constexpr bool PADDED = KS <= 13;  // contiguous slots: rows at an odd pitch in LDS (conflict-free fragment reads)
     static constexpr int NI = 2 * KS + 1;  // contiguous slots: 1 KiB DMA instructions per tile (32 rows at a padded pitch)
-    static constexpr int SLOT = ROWS ? 32 * PITCH : 1024 * NI;
+    // row-staged slots are filled like the contiguous ones: 64 consecutive 16-byte units of the slot per DMA instruction,
+    // every lane fetching ITS unit from wherever it lies in the capture (unit q = unit q % UNITS_ROW of row q / UNITS_ROW; a
+    // row's padding unit and the units behind row 31 re-fetch a neighbour) -- 32 (4 KS + 1) / 64 instructions per tile
+    // instead of one per row with 4 KS of 64 lanes active (2 k steps: 5 instead of 32)
+    static constexpr int UNITS_ROW = PITCH / 16;
+    static constexpr int NI_ROWS = (32 * UNITS_ROW + 63) / 64;
+    static constexpr int SLOT = ROWS ? (32 * PITCH > 1024 * NI_ROWS ? 32 * PITCH : 1024 * NI_ROWS) : 1024 * NI;
     static constexpr bool LOADERS = !PAIR && (ROWS || KS <= IQA_RING_LOADERS_MAX_KS);  // two extra waves feed the ring and emit (needs <= 168 registers)
-    static constexpr int NDMA = ROWS ? 32 : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
+    static constexpr int NDMA = ROWS ? NI_ROWS : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
     static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
     static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
@@ -298,22 +304,31 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
     constexpr int R = G::R, SLOT = G::SLOT;
     constexpr bool STREAM = !(DBG & 16);
     const int cp = c.cp;
-    int soff[ROWS ? 1 : G::NI];
+    int soff[ROWS ? G::NI_ROWS : G::NI];
     if constexpr (!ROWS) {
 #pragma unroll
         for (int i = 0; i < G::NI; ++i) soff[i] = ring_src_off(i, c.lane, c.row_units, c.pitch_units);
+    } else {
+        const int row_bytes = static_cast<int>(c.tile_bytes >> 5);
+#pragma unroll
+        for (int i = 0; i < G::NI_ROWS; ++i) {
+            const int q = 64 * i + c.lane;
+            int r = q / G::UNITS_ROW;
+            int u = q - r * G::UNITS_ROW;
+            if (r > 31) {
+                r = 31;
+                u = G::UNITS_ROW - 2;
+            }
+            soff[i] = r * row_bytes + min(u, G::UNITS_ROW - 2) * 16;  // (the last data unit again for the padding unit)
+        }
     }
     auto issue_tile = [&](int tile, int slot) {
         const char *src = c.stream0 + static_cast<long long>(min(tile, c.tiles - 1)) * c.tile_bytes;
         char *dst = c.smem + (slot * 2 + cp) * SLOT;
         if constexpr (ROWS) {
-            // one DMA per data row: the first KBYTES*KS/16 lanes fetch the bytes of this pass's k steps
-            const long long row_bytes = c.tile_bytes >> 5;
-            if (c.lane < (G::KBYTES / 16) * KS) {
 #pragma unroll
-                for (int j = 0; j < 32; ++j)
-                    __builtin_amdgcn_global_load_lds(src + j * row_bytes, (ring_lds_t *)(dst + j * G::PITCH), 16, 0, IQA_RING_DMA_AUX);
-            }
+            for (int i = 0; i < G::NI_ROWS; ++i)
+                __builtin_amdgcn_global_load_lds(src + soff[i], (ring_lds_t *)(dst + i * 1024), 16, 0, IQA_RING_DMA_AUX);
         } else {
 #pragma unroll
             for (int i = 0; i < G::NI; ++i)
@@ -655,7 +670,7 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     const long long row_bytes = static_cast<long long>(FB) * a.D;
     c.tile_bytes = 32 * row_bytes;
     const char *stream = reinterpret_cast<const char *>(a.raw) + FB * ((c.m0 - MF_Q - a.col_shift) * a.D + 1 - a.consumed) +
-                         (ROWS ? c.lane * 16 + G::KBYTES * a.k_first : 0);
+                         (ROWS ? G::KBYTES * a.k_first : 0);
     c.row_units = static_cast<int>(row_bytes >> 4);
     c.pitch_units = G::PADDED ? (c.row_units | 1) : c.row_units;  // odd: conflict-free fragment reads (see RingGeo)
     c.lane_off = c.col * (ROWS ? G::PITCH : 16 * c.pitch_units) + (G::KBYTES / 2) * c.h;
