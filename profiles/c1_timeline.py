@@ -4,7 +4,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 big = [i for i, r in enumerate(rows) if "k_channelize_mfma" in r["Kernel_Name"] and "short" not in r["Kernel_Name"]
-       and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 30_000]
+       and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 12_000]
 i0, i1 = big[-4], big[-2]
 t0, prev_end = int(rows[i0]["Start_Timestamp"]), None
 for r in rows[i0 : i1 + 1]:
