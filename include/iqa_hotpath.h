@@ -154,6 +154,10 @@ int64_t iqa_mfma_afrag_bytes(int32_t decimation);
  * contiguous bytes, so the last output of a ring pass must satisfy
  * (m_last - 1)*D + 512*ceil(2D/32) < consumed + n_frames. */
 int64_t iqa_mfma_ring_bytes(int32_t decimation);
+/* LDS bytes of a workgroup of the ring kernel iqa_mfma_ring_mode selects for this pass (0: none): a launch may give a CU
+ * as many workgroups as fit into its 160 KiB (two at <= 3 k steps -- short rows, e.g. D = 26 at 2.5 MS/s -- where a
+ * second one hides the first one's per-round latency). */
+int64_t iqa_mfma_ring_lds_bytes(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32);
 /* Which ring kernel covers a pass over k steps [k_first, k_first + k_count) at this decimation: 0 = none (int16: use
  * the per-lane kernel, reserved = 0; uint8: use iqa_channelize), 1 = contiguous slots (int16, all k steps in one
  * pass, D % 4 == 0, D <= 256), 2 = row-staged slots (int16 or uint8, any D, k_count <= 11, int32 sums only:

@@ -76,6 +76,7 @@ _SIGNATURES = {
                                       c_int64, c_int64, c_void_p, c_void_p]),
     "iqa_mfma_afrag_bytes": (c_int64, [c_int32]),
     "iqa_mfma_ring_bytes": (c_int64, [c_int32]),
+    "iqa_mfma_ring_lds_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "iqa_mfma_ring_mode": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "iqa_channelize_mfma": (ctypes.c_int, [ctypes.POINTER(ChanParams), ctypes.POINTER(MfmaParams), c_void_p, c_void_p,
                                            c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),

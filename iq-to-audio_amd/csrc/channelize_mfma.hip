@@ -213,6 +213,16 @@ extern "C" int64_t iqa_mfma_ring_bytes(int32_t decimation)
     return static_cast<int64_t>(mfma_ring_lds_bytes((2 * decimation + 31) / 32, false, false));
 }
 
+extern "C" int64_t iqa_mfma_ring_lds_bytes(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32)
+{
+    // LDS bytes of a workgroup of the ring kernel that iqa_mfma_ring_mode selects for this pass (0: none applies)
+    if (decimation < 1 || (fmt != IQA_FMT_S16 && fmt != IQA_FMT_U8)) return 0;
+    const int ks_all = (2 * decimation + 31) / 32;
+    const int ks = k_count > 0 ? k_count : ks_all - k_first;
+    const int mode = mfma_ring_mode(decimation, k_first, ks, acc32 == 0, fmt == IQA_FMT_U8);
+    return mode ? static_cast<int64_t>(mfma_ring_lds_bytes(ks, mode == 2, fmt == IQA_FMT_U8)) : 0;
+}
+
 extern "C" int32_t iqa_mfma_ring_mode(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32)
 {
     if (decimation < 1 || (fmt != IQA_FMT_S16 && fmt != IQA_FMT_U8)) return 0;

@@ -233,13 +233,22 @@ class _ChannelKernel:
     launch_blocks = 256
 
     @classmethod
-    def _block_outputs(cls, n_out: int, rmax: int) -> int:
+    def _block_outputs(cls, n_out: int, rmax: int, per_cu: int = 1) -> int:
         """Outputs per block for a launch of ``n_out`` outputs: as large as LDS allows, but chosen so that the
         number of blocks is a multiple of the 256 CUs (one block per CU, no ragged last round).  The ring kernel
-        has no LDS bound (``rmax`` huge): every CU gets ONE contiguous range of the launch."""
-        rounds = max(1, -(-n_out // (cls.launch_blocks * rmax)))
-        per = -(-n_out // (cls.launch_blocks * rounds))
+        has no LDS bound (``rmax`` huge): every CU gets ONE contiguous range of the launch -- ``per_cu`` of them where
+        that many of its workgroups fit into a CU's LDS (short rows: <= 3 k steps)."""
+        blocks = cls.launch_blocks * per_cu
+        rounds = max(1, -(-n_out // (blocks * rmax)))
+        per = -(-n_out // (blocks * rounds))
         return int(min(rmax, max(512, -(-per // 32) * 32)))
+
+    def _workgroups_per_cu(self, ps, variant: str) -> int:
+        if variant != "ring":
+            return 1
+        lds = int(N.lib().iqa_mfma_ring_lds_bytes(P.FMT_CODE[self.plan.fmt], self.plan.decimation, ps.k_first, ps.k_count,
+                                                  1 if self.ring_acc32 else 0))
+        return 2 if 0 < lds <= 80 * 1024 else 1
 
     def _valu(self, raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev):
         if n_out > 0:
@@ -277,7 +286,8 @@ class _ChannelKernel:
         partial = D.empty(2 * n_int, "float64") if len(mp.passes) > 1 else None
         for i, (ps, prm) in enumerate(zip(mp.passes, self.mfma_params)):
             last = i == len(mp.passes) - 1
-            rng = self._block_outputs(n_int, self._range_max(ps.k_count, self._pass_variant[i]))
+            rng = self._block_outputs(n_int, self._range_max(ps.k_count, self._pass_variant[i]),
+                                      self._workgroups_per_cu(ps, self._pass_variant[i]))
             if self._pass_variant[i] == "ring" and min_block < 512:  # short launches: more, smaller blocks
                 rng = max(min_block, min(rng, -(-(-(-n_int // 256)) // 32) * 32))
             prm.outputs_per_block = rng
