@@ -491,7 +491,7 @@ def test_captured_step_replays_to_the_same_audio(A):
             assert r["sign"] == sign
             assert np.array_equal(r["pcm_host"].numpy(), pcm), rep
             assert torch.equal(r["audio"], audio)
-    assert len(runner._graphs) == 2
+    assert 2 <= len(runner._graphs) <= 2 * runner.SLOTS  # one graph per (buffer, slot) the rounds above have touched
     # the same fixed buffer with another capture in it: the replay reads what is there now
     bufs[0].copy_(D.to_device(caps[2].reshape(-1), "int16"))
     torch.cuda.synchronize()
