@@ -497,6 +497,46 @@ def test_resampler_matches_spec(A):
     np.testing.assert_allclose(y5, O.resample_48k(x, 50e6 / 521), rtol=0, atol=2e-7)
 
 
+@pytest.mark.parametrize("mode,agc", [("nfm", True), ("am", True), ("usb", True), ("lsb", False)])
+def test_demodulate_from_reset_equals_reset_then_demodulate(A, mode, agc):
+    """iqa_demodulate_from_reset (what ChannelDemod.process calls after a reset) against the explicit way: the pristine
+    state image copied over a used decoder's state block, then iqa_demodulate -- audio, outgoing state and peak bit for
+    bit, the per-chunk sums to rounding, for a block whose chunk starts make the SSB AGC restart inside it."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd.processing import ChannelDemod
+
+    rng = np.random.default_rng(21)
+    n, fs_ch = 300_001, 96_153.8
+    t = np.arange(n) / fs_ch
+    z = (0.3 * np.exp(2j * np.pi * (900.0 * t + 2.0 * np.sin(2 * np.pi * 3.0 * t))) * (1.0 + 0.4 * np.sin(2 * np.pi * 440.0 * t))
+         + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))).astype(np.complex64)
+    z_dev = D.to_device(z, "complex64")
+    starts = np.array([0, 40_330, 80_660, 120_990, 161_320, 201_650, 241_980, 282_310], dtype=np.int64)
+    dem = ChannelDemod(mode, fs_ch, deemph_us=300.0, agc_enabled=agc)
+    used = D.empty(n, "float32")
+    dem.process(z_dev[: n // 2].contiguous() * 0.5, np.array([0], dtype=np.int64), used)  # the decoder has seen something
+    # (a) the explicit way
+    dem.prepare(n, starts)
+    dem._alloc_block(len(starts))  # a pristine block of the right size (uploads the image)
+    dem._from_reset, dem._fresh, dem.chunk_sumsq = False, True, []
+    a_audio = D.empty(n, "float32")
+    dem.process(z_dev, starts, a_audio)
+    a_state, a_peak, a_sums = dem.state_dev.clone(), dem.peak, dem.chunk_sumsq[-1][0].clone()
+    # (b) a used decoder, reset() (no copy), process (iqa_demodulate_from_reset)
+    dem.process(z_dev[: n // 3].contiguous(), np.array([0], dtype=np.int64), used)
+    dem.reset()
+    assert dem._from_reset and dem.peak == 0.0
+    b_audio = D.empty(n, "float32")
+    dem.process(z_dev, starts, b_audio)
+    assert torch.equal(a_audio, b_audio)
+    assert torch.equal(a_state, dem.state_dev) and a_peak == dem.peak
+    # (the sums are float64 atomics of several workgroups per slot: equal up to the order of additions)
+    assert torch.allclose(a_sums, dem.chunk_sumsq[-1][0], rtol=1e-12, atol=0.0)
+    assert a_peak > 0.0 and float(a_sums.sum()) > 0.0
+
+
 @pytest.mark.parametrize("fs_ch", [150_000.0, 250_000.0, 192_000.0, 48_000.0, 44_100.0, 24_000.0, 8_000.0, 96_000.0, 131_071.0])
 def test_resampler_other_ratios(A, fs_ch):
     """Channel rates other than the 96 kHz class: longer polyphase rows (the 24 / 32 / 48 taps-per-lane builds; past the
