@@ -177,6 +177,8 @@ int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_params *q, cons
  * Lanes of the same stretch of the capture run at the same time on the CUs of one XCD, so the stretch crosses the
  * fabric once (channelize_ring.hip).  int32 sums only: fragments from dsp_plan.plan_mfma(acc32=True);
  * iqa_mfma_ring_mode(fmt, D, k_first, k_count, 1) must be non-zero.  At most 16 lanes per call.
+ * Two lanes may share a q_group (their data rows): a group's taps and the residue of their quantisation as a second lane
+ * (the "fine" precision of the host pipeline, dsp_plan.plan_mfma(residual=True)).
  * A filter with several tap-row groups is several lanes with finalize = 0, each writing its raw sums to its own
  * partial_out_dev; iqa_mfma_combine adds them in group order and finishes z.  A decimation whose k steps need several
  * passes is several calls chained through partial_in_dev / partial_out_dev per lane, as with iqa_channelize_mfma.
@@ -216,7 +218,8 @@ int iqa_channelize_mfma_pairs(int32_t fmt, int32_t decimation, int32_t k_first, 
                               int64_t n_out, void *stream);
 int32_t iqa_mfma_ring_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count);
 /* z[m_first + i] = finish(sum_k partials_dev[k][i]): the float32 conversion, conjugation, rotation and scaling of the
- * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..8 buffers of double2[n_out],
+ * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..16 buffers of double2[n_out]
+ * (a filter's tap-row groups -- and, with residual quantisation, each group's second lane: dsp_plan.plan_mfma(residual=True)),
  * or -- raw_scale != NULL -- of int32[2*n_out] written by lanes with raw_partials = 1; raw_scale is a HOST array of
  * n_partials triples {unit, c_re, c_im} (the lane's own values), applied as (256*v + c)*unit before the sum. */
 int iqa_mfma_combine(const iqa_chan_params *p, const void *const *partials_dev, int32_t n_partials,
@@ -253,6 +256,15 @@ int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *power_dev, 
  * accumulated: power_dev may be mapped pinned host memory) -- the two mixer-sign probes of choose_mix_sign
  * (processing.py:623-663) side by side. */
 int iqa_mean_power_batch(const void *z_dev, int64_t n_each, int32_t parts, int64_t skip, void *power_dev, void *stream);
+
+/* Wideband level of raw capture frames: *mean_square_out (double[1], WRITTEN by one workgroup: device or mapped pinned
+ * host memory) = mean of value^2 over up to 65536 values sampled evenly from raw_dev[0 : n_values] (int16 / uint8 - 128 /
+ * float32 values, I and Q alike; raw_dev 16-byte aligned).  The caller scales: wideband RMS of the complex samples =
+ * sqrt(2 * mean_square) * ingest scale.  It is the reference level of the precision guard of the fixed-point
+ * channelizers (a channel far below the wideband level is re-run at a finer precision); the reference needs none -- its
+ * filter runs in complex128 whatever the levels, processing.py:300-346 -- and the warm-up block it is measured on is the
+ * one choose_mix_sign inspects, processing.py:1027-1043. */
+int iqa_raw_level(int32_t fmt, const void *raw_dev, int64_t n_values, void *mean_square_out, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Demodulators (channel rate)                                                 *

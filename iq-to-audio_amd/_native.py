@@ -92,6 +92,7 @@ _SIGNATURES = {
     "iqa_decimate": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
     "iqa_mean_power": (ctypes.c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "iqa_mean_power_batch": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p]),
+    "iqa_raw_level": (ctypes.c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "iqa_quadrature": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "iqa_envelope": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "iqa_real_part": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

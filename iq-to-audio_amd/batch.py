@@ -14,8 +14,12 @@ import numpy as np
 from . import _dev as D
 from . import _native as N
 from . import dsp_plan as P
-from .processing import (ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, immutable_taps, probe_targets,
-                         reserve_pinned_scalars)
+from .processing import (PRECISION_GUARD, ChannelBank, ChannelDemod, Channelizer, MixSignProbe, Resampler48k, _ChannelKernel,
+                         base_precision, immutable_taps, pick_precision, probe_targets, reserve_pinned_scalars)
+
+
+def _rank(precision: str) -> int:
+    return _ChannelKernel.PRECISIONS.index(precision)
 
 
 class ResidentCaptureRunner:
@@ -36,7 +40,11 @@ class ResidentCaptureRunner:
       demodulator and resampler back to back.
 
     ``collect`` waits for a capture, reads the probe back and, if it chose -1 after all, re-runs that capture
-    with the right sign before returning.  Nothing is cached between captures except the plans.
+    with the right sign before returning.  The same read-back carries the precision guard of the file pipeline
+    (``processing.pick_precision``): the probe's channel power against the wideband level of the warm-up block; an NFM
+    channel too far below it for the precision the capture ran at is re-run at the one that clears it.  The last probed
+    sign and precision are the next capture's speculation.  Nothing else is cached between captures except the plans.
+    SSB with the AGC on starts at the "full" precision (``processing.base_precision``).
     """
 
     #: submit(resident=True): demodulator + resampler of capture i on their own stream, beside the channelizer of capture i + 1
@@ -45,12 +53,20 @@ class ResidentCaptureRunner:
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
-                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None):
+                 fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, precision: str | None = None,
+                 precision_guard: float | None = None):
+        """``precision``: the channelizer precision every capture starts at (default: by demodulator,
+        ``processing.base_precision``); ``precision_guard``: see ``processing.PRECISION_GUARD`` (0 = off)."""
         torch = D.torch_mod()
         self.taps, self.fs, self.f_off, self.d, self.fs_ch = immutable_taps(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
         self.chunk, self.n_frames, self.fmt, self.iq_order = int(chunk), int(n_frames), fmt, iq_order
         self.demod_args = dict(mode=demod_mode, deemph_us=deemph_us, agc_enabled=agc_enabled)
         self.override = mix_sign_override if mix_sign_override in (1, -1) else None
+        self.base_precision = precision or base_precision(demod_mode, agc_enabled)
+        self.guard = PRECISION_GUARD if precision_guard is None else float(precision_guard)
+        self._guarded = bool(self.guard) and self.override is None and (demod_mode or "").lower() in ("nfm", "fm")
+        self._spec_sign, self._spec_precision = 1, self.base_precision  # what the next capture is run with before its probe is read
+        self.redone = dict(sign=0, precision=0)  # captures re-run in collect, by cause
         self.n_dec = -(-self.n_frames // self.d)
         self.starts = P.chunk_output_starts(self.chunk, self.d, 0, self.n_frames)
         self.rs = Resampler48k(self.fs_ch)
@@ -79,13 +95,24 @@ class ResidentCaptureRunner:
         # record between two kernels of a stream costs ~7 us on this part
         with D.on_stream(self.aux if resident else self.compute, self.compute):
             return MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order,
-                                record_done=False)
+                                record_done=False, measure_level=self._guarded)
 
-    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None, resident: bool = False, probe=None):
+    def _kernel_for(self, sign: int):
+        return lambda name: Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
+                                        fmt=self.fmt, iq_order=self.iq_order, precision=name)._kernel
+
+    def _needed_precision(self, probe, sign: int) -> str:
+        """What the precision guard asks for, given a probe that has been read (``power``, ``wideband_rms`` set)."""
+        if not self._guarded or probe is None:
+            return self.base_precision
+        return pick_precision(self._kernel_for(sign), self.base_precision, self.demod_args["mode"], probe.power, probe.wideband_rms,
+                              self.guard)
+
+    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None, resident: bool = False, probe=None, precision: str | None = None):
         """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
         torch = D.torch_mod()
         chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
-                           fmt=self.fmt, iq_order=self.iq_order)
+                           fmt=self.fmt, iq_order=self.iq_order, precision=precision or self.base_precision)
         chan.plan_ahead()
         dem = slot["dem"]
         side = self.aux if resident else None
@@ -137,7 +164,7 @@ class ResidentCaptureRunner:
         done = torch.cuda.Event()
         # tail_done: recorded lazily (tail_event) -- the next capture's gate lies behind it anyway
         ticket = dict(chan=chan, dem=dem, pcm=pcm, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel,
-                      slot=slot, egress_queued=False, resident=resident)
+                      slot=slot, egress_queued=False, resident=resident, precision=chan.precision)
         self._egress_pending = ticket
         return ticket
 
@@ -206,9 +233,9 @@ class ResidentCaptureRunner:
             # of this slot's buffers finished before that
             self.aux.wait_event(self._ring_done)
         probe = self._probe(raw_dev, resident)
-        sign = self.override if self.override is not None else 1
+        sign = self.override if self.override is not None else self._spec_sign
         halo = (enclosing, int(lead_frames)) if enclosing is not None else None
-        ticket = self._chain(raw_dev, slot, sign, events, halo, resident, probe)
+        ticket = self._chain(raw_dev, slot, sign, events, halo, resident, probe, self._spec_precision)
         ticket.update(probe=probe, sign=sign, raw=raw_dev, halo=halo)
         slot["busy"] = ticket
         return ticket
@@ -224,15 +251,17 @@ class ResidentCaptureRunner:
     # again the ordinary way with the right sign.
 
     def _captured_step(self, raw_dev, slot, halo):
-        """Queue the whole step for sign +1 on the current (capturing) stream; returns what collect needs."""
-        chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=self.override or 1, decimation=self.d,
-                           fmt=self.fmt, iq_order=self.iq_order)
+        """Queue the whole step for the speculated sign / precision on the current (capturing) stream; returns what collect needs."""
+        sign = self.override or self._spec_sign
+        chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
+                           fmt=self.fmt, iq_order=self.iq_order, precision=self._spec_precision)
         chan.plan_ahead()
         dem = slot["dem"]
         probe = None
         if self.override is None:
             warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
-            probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order, record_done=False)
+            probe = MixSignProbe(warm, self.fs, self.f_off, self.taps, self.d, fmt=self.fmt, iq_order=self.iq_order, record_done=False,
+                                 measure_level=self._guarded)
         dem.reset(force=True)
         dem.prepare(self.n_dec, self.starts)
         chan.process(raw_dev, out_dev=slot["z"], last_block=True, halo=halo)
@@ -243,7 +272,7 @@ class ResidentCaptureRunner:
         # config 1: 0.097 -> 0.0935 ms per capture)
         N.call("iqa_trickle_copy", N.ptr(pcm), c_void_p(host.data_ptr()), c_int64(host.numel() * host.element_size()),
                c_int32(max(self.egress_workgroups, 64)), N.stream_ptr())
-        return dict(chan=chan, dem=dem, pcm=pcm, probe=probe, kernel=chan._kernel.last_kernel)
+        return dict(chan=chan, dem=dem, pcm=pcm, probe=probe, kernel=chan._kernel.last_kernel, sign=sign, precision=chan.precision)
 
     def submit_captured(self, raw_dev, enclosing=None, lead_frames: int = 0) -> dict:
         """``submit`` for a capture in a fixed buffer: the first call per (buffer, slot) runs the step once the ordinary way
@@ -257,12 +286,18 @@ class ResidentCaptureRunner:
         if slot["busy"] is not None:
             self.collect(slot["busy"])
         halo = (enclosing, int(lead_frames)) if enclosing is not None else None
-        key = (int(raw_dev.data_ptr()), index, None if enclosing is None else int(enclosing.data_ptr()), int(lead_frames))
+        def graph_key():  # (a graph holds the speculation it was captured with)
+            return (int(raw_dev.data_ptr()), index, None if enclosing is None else int(enclosing.data_ptr()), int(lead_frames),
+                    self._spec_sign, self._spec_precision)
+
+        key = graph_key()
         graphs = self.__dict__.setdefault("_graphs", {})
         entry = graphs.get(key)
         if entry is None:
             # once the ordinary way, in this very slot: plans, tap uploads and the pinned probe slot exist afterwards
+            # (and the capture's own probe has set the speculation the graph is captured with)
             self.collect(self.submit(raw_dev, enclosing=enclosing, lead_frames=lead_frames))
+            key = graph_key()
             torch.cuda.synchronize()
             reserve_pinned_scalars(1)
             g = torch.cuda.CUDAGraph()
@@ -277,7 +312,7 @@ class ResidentCaptureRunner:
         done.record()
         ticket = dict(chan=entry["chan"], dem=entry["dem"], pcm=entry["pcm"], done=done, tail_done=done, kernel=entry["kernel"],
                       slot=slot, egress_queued=True, resident=False, probe=None, graph_probe=entry["probe"],
-                      sign=self.override or 1, raw=raw_dev, halo=halo)
+                      sign=entry["sign"], precision=entry["precision"], raw=raw_dev, halo=halo)
         slot["busy"] = ticket
         return ticket
 
@@ -294,13 +329,18 @@ class ResidentCaptureRunner:
             if slot["busy"] is not None:
                 self.collect(slot["busy"])
         halos = [(enc, int(lead)) if enc is not None else None for _, enc, lead in captures]
-        key = ("batch",) + tuple((int(raw.data_ptr()), None if enc is None else int(enc.data_ptr()), int(lead)) for raw, enc, lead in captures)
+        def graph_key():
+            return ("batch", self._spec_sign, self._spec_precision) + tuple((int(raw.data_ptr()), None if enc is None else int(enc.data_ptr()), int(lead))
+                                                                            for raw, enc, lead in captures)
+
+        key = graph_key()
         graphs = self.__dict__.setdefault("_graphs", {})
         entry = graphs.get(key)
         if entry is None:
             self._next = 0
             for raw, enc, lead in captures:  # once the ordinary way, each in its slot
                 self.collect(self.submit(raw, enclosing=enc, lead_frames=lead))
+            key = graph_key()
             torch.cuda.synchronize()
             reserve_pinned_scalars(len(captures))
             g = torch.cuda.CUDAGraph()
@@ -315,7 +355,8 @@ class ResidentCaptureRunner:
         tickets = []
         for (raw, _, _), slot, halo, p_ in zip(captures, self.slots, halos, entry["parts"]):
             t = dict(chan=p_["chan"], dem=p_["dem"], pcm=p_["pcm"], done=done, tail_done=done, kernel=p_["kernel"], slot=slot,
-                     egress_queued=True, resident=False, probe=None, graph_probe=p_["probe"], sign=self.override or 1, raw=raw, halo=halo)
+                     egress_queued=True, resident=False, probe=None, graph_probe=p_["probe"], sign=p_["sign"], precision=p_["precision"],
+                     raw=raw, halo=halo)
             slot["busy"] = t
             tickets.append(t)
         return tickets
@@ -329,9 +370,13 @@ class ResidentCaptureRunner:
         if ticket.get("graph_probe") is not None:  # a replayed step: its probes' powers sit in the graph's pinned slot
             ticket["done"].synchronize()
             sign = ticket["graph_probe"].peek()
-            if sign != ticket["sign"]:  # the captured step assumed +1: this capture again, the ordinary way
+            need = self._needed_precision(ticket["graph_probe"], sign)
+            self._spec_sign, self._spec_precision = sign, need
+            if sign != ticket["sign"] or _rank(need) > _rank(ticket["precision"]):
+                # the captured step assumed another sign / a coarser precision: this capture again, the ordinary way
                 self.replays_redone = getattr(self, "replays_redone", 0) + 1
-                redo = self._chain(ticket["raw"], slot, sign, None, ticket.get("halo"), False)
+                self.redone["sign" if sign != ticket["sign"] else "precision"] += 1
+                redo = self._chain(ticket["raw"], slot, sign, None, ticket.get("halo"), False, precision=need)
                 self._flush_egress()
                 ticket.update(redo, sign=sign, probe=None, raw=ticket["raw"], graph_probe=None)
         if D.current_raw_stream() != self._compute_raw:  # (it may queue the D2H, or the whole capture again)
@@ -341,10 +386,14 @@ class ResidentCaptureRunner:
             self._flush_egress()
         if ticket["probe"] is not None:
             sign = ticket["probe"].result()
-            if sign != ticket["sign"]:  # the speculation was wrong: this capture again, with the sign the probe chose
+            need = self._needed_precision(ticket["probe"], sign)
+            self._spec_sign, self._spec_precision = sign, need
+            if sign != ticket["sign"] or _rank(need) > _rank(ticket["precision"]):
+                # the speculation was wrong: this capture again, with the sign the probe chose / at the precision the guard asks for
+                self.redone["sign" if sign != ticket["sign"] else "precision"] += 1
                 ticket["done"].synchronize()
                 probe, raw = ticket["probe"], ticket["raw"]
-                redo = self._chain(raw, slot, sign, None, ticket.get("halo"), ticket.get("resident", False))
+                redo = self._chain(raw, slot, sign, None, ticket.get("halo"), ticket.get("resident", False), precision=need)
                 self._flush_egress()
                 ticket.update(redo, sign=sign, probe=probe, raw=raw)
         ticket["done"].synchronize()
@@ -353,7 +402,7 @@ class ResidentCaptureRunner:
         if slot["busy"] is ticket:
             slot["busy"] = None
         ticket["result"] = dict(pcm_host=slot["pcm_host"], sign=int(sign), audio=slot["audio"], z=slot["z"],
-                                kernel=ticket["kernel"], demod=ticket["dem"], done=ticket["done"])
+                                kernel=ticket["kernel"], demod=ticket["dem"], done=ticket["done"], precision=ticket["precision"])
         return ticket["result"]
 
 
@@ -365,7 +414,10 @@ class ResidentBankRunner:
     channelizer over the capture for all targets (:class:`processing.ChannelBank`, run speculatively for sign +1 like
     :class:`ResidentCaptureRunner`), then per target the fused demodulator + writer clip, the 48 kHz resampler with PCM16
     output and the copy of that PCM16 into pinned host memory -- all on the caller's stream, no host<->device
-    synchronisation.  ``collect`` waits, reads the probes back and re-runs the targets whose probe chose -1.
+    synchronisation.  ``collect`` waits, reads the probes back and re-runs the targets whose probe chose the other sign
+    or whose level asks for a finer precision (the precision guard, ``processing.pick_precision``); what a target's last
+    probe said is the next capture's speculation.  SSB targets with the AGC on run at "full" precision (their own chained
+    passes behind the shared one, ``processing.base_precision``).
     """
 
     SLOTS = 3  # output buffers in flight: with the tails of capture i finishing somewhere inside the pass of capture i + 1, a
@@ -373,9 +425,9 @@ class ResidentBankRunner:
     overlap_tails = True  # the per-target chains of capture i beside the channelizer pass of capture i + 1
 
     def __init__(self, targets: list, *, sample_rate: float, n_frames: int, chunk_size: int = 1_048_576,
-                 fs_ch_target: float = 96_000.0, fmt: str = "s16", iq_order: str = "iq"):
+                 fs_ch_target: float = 96_000.0, fmt: str = "s16", iq_order: str = "iq", precision_guard: float | None = None):
         """``targets``: dicts with ``freq_offset``, and optionally ``bandwidth`` (12 500), ``demod_mode`` ("nfm"),
-        ``deemph_us`` (300), ``agc_enabled`` (True), ``mix_sign`` (None = probe)."""
+        ``deemph_us`` (300), ``agc_enabled`` (True), ``mix_sign`` (None = probe), ``precision`` (None = by demodulator)."""
         torch = D.torch_mod()
         if not targets:
             raise ValueError("at least one target is required")
@@ -388,22 +440,37 @@ class ResidentBankRunner:
         self.n48 = self.rs.plan.n_out(self.n_dec)
         self.targets = []
         for t in targets:
-            spec = dict(bandwidth=12_500.0, demod_mode="nfm", deemph_us=300.0, agc_enabled=True, mix_sign=None)
+            spec = dict(bandwidth=12_500.0, demod_mode="nfm", deemph_us=300.0, agc_enabled=True, mix_sign=None, precision=None)
             spec.update(t)
             spec["taps"] = immutable_taps(P.design_channel_filter(self.fs, spec["bandwidth"], self.d))
+            spec["base_precision"] = spec["precision"] or base_precision(spec["demod_mode"], spec["agc_enabled"])
             self.targets.append(spec)
+        self.guard = PRECISION_GUARD if precision_guard is None else float(precision_guard)
+        self._spec_sign = [1] * len(self.targets)
+        self._spec_precision = [s["base_precision"] for s in self.targets]
+        self.redone = dict(sign=0, precision=0)
         self.slots = []
         for _ in range(self.SLOTS):
             per = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
                         pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(),
                         dem=ChannelDemod(s["demod_mode"], self.fs_ch, deemph_us=s["deemph_us"], agc_enabled=s["agc_enabled"]))
                    for s in self.targets]
-            self.slots.append(dict(per=per, busy=None, probe_host=torch.empty(2 * len(self.targets), dtype=torch.float64).pin_memory()))
+            # (two powers per target + the wideband level of the warm-up block)
+            self.slots.append(dict(per=per, busy=None, probe_host=torch.zeros(2 * len(self.targets) + 1, dtype=torch.float64).pin_memory()))
         self._next = 0
 
-    def _channelizer(self, spec, sign: int) -> Channelizer:
+    def _channelizer(self, spec, sign: int, precision: str | None = None) -> Channelizer:
         return Channelizer(spec["taps"], sample_rate=self.fs, freq_offset=spec["freq_offset"], mix_sign=sign, decimation=self.d,
-                           fmt=self.fmt, iq_order=self.iq_order)
+                           fmt=self.fmt, iq_order=self.iq_order, precision=precision or spec["base_precision"])
+
+    def _guarded(self, spec) -> bool:
+        return bool(self.guard) and spec["mix_sign"] not in (1, -1) and (spec["demod_mode"] or "").lower() in ("nfm", "fm")
+
+    def _needed_precision(self, spec, probe, sign: int) -> str:
+        if probe is None or not self._guarded(spec):
+            return spec["base_precision"]
+        return pick_precision(lambda name: self._channelizer(spec, sign, name)._kernel, spec["base_precision"], spec["demod_mode"],
+                              probe.power, probe.wideband_rms, self.guard)
 
     def _finish_target(self, per, raw_unused=None) -> None:
         """Demodulator + writer clip, 48 kHz PCM16, copy to the host: for one target's z."""
@@ -440,10 +507,12 @@ class ResidentBankRunner:
                 probes[i] = pr
         else:
             probes = [None if s["mix_sign"] in (1, -1) else
-                      MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order)
+                      MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order,
+                                   measure_level=self._guarded(s))
                       for s in self.targets]
-        signs = [s["mix_sign"] if s["mix_sign"] in (1, -1) else 1 for s in self.targets]
-        chans = [self._channelizer(s, sg) for s, sg in zip(self.targets, signs)]
+        signs = [s["mix_sign"] if s["mix_sign"] in (1, -1) else sp for s, sp in zip(self.targets, self._spec_sign)]
+        precisions = list(self._spec_precision)
+        chans = [self._channelizer(s, sg, pr) for s, sg, pr in zip(self.targets, signs, precisions)]
         for c in chans:
             c.plan_ahead()
         halo = (enclosing, int(lead_frames)) if enclosing is not None else None
@@ -474,8 +543,8 @@ class ResidentBankRunner:
                 self._finish_target(per)
             done = torch.cuda.Event()
             done.record()
-        ticket = dict(slot=slot, probes=probes, signs=signs, raw=raw_dev, halo=halo, done=done, launch=bank.last_launch,
-                      kernel=chans[0]._kernel.last_kernel, collected=False)
+        ticket = dict(slot=slot, probes=probes, signs=signs, precisions=[c.precision for c in chans], raw=raw_dev, halo=halo, done=done,
+                      launch=bank.last_launch, kernel=chans[0]._kernel.last_kernel, collected=False)
         slot["busy"] = ticket
         return ticket
 
@@ -491,9 +560,15 @@ class ResidentBankRunner:
             if probe is None:
                 continue
             sign = probe.result()
-            if sign != ticket["signs"][i]:  # the speculation was wrong for this target: its channel again, alone
+            need = self._needed_precision(spec, probe, sign)
+            self._spec_sign[i], self._spec_precision[i] = sign, need
+            if sign != ticket["signs"][i] or _rank(need) > _rank(ticket["precisions"][i]):
+                # the speculation was wrong for this target (sign, or a level that asks for a finer precision): its channel again, alone
+                self.redone["sign" if sign != ticket["signs"][i] else "precision"] += 1
                 ticket["signs"][i] = sign
-                self._channelizer(spec, sign).process(ticket["raw"], out_dev=per["z"], last_block=True, halo=ticket["halo"])
+                chan = self._channelizer(spec, sign, need)
+                ticket["precisions"][i] = chan.precision
+                chan.process(ticket["raw"], out_dev=per["z"], last_block=True, halo=ticket["halo"])
                 self._finish_target(per)
                 redo = True
         if redo:
@@ -502,8 +577,8 @@ class ResidentBankRunner:
         ticket["raw"] = None
         if slot["busy"] is ticket:
             slot["busy"] = None
-        ticket["result"] = [dict(pcm_host=per["pcm_host"], audio=per["audio"], z=per["z"], sign=int(sg), demod=per["dem"])
-                            for per, sg in zip(slot["per"], ticket["signs"])]
+        ticket["result"] = [dict(pcm_host=per["pcm_host"], audio=per["audio"], z=per["z"], sign=int(sg), demod=per["dem"], precision=pr)
+                            for per, sg, pr in zip(slot["per"], ticket["signs"], ticket["precisions"])]
         return ticket["result"]
 
 

@@ -471,8 +471,8 @@ extern "C" int32_t iqa_mfma_ring_pairs(int32_t fmt, int32_t decimation, int32_t 
 // same conversion, rotation and scaling as the kernels' own emission: z[m_first + i].
 namespace iqa {
 struct CombineArgs {
-    const double2 *part[8];
-    double unit[8], c_re[8], c_im[8];  // raw != 0: part[k] holds int2 sums, scaled here exactly as the kernels' emission does
+    const double2 *part[16];
+    double unit[16], c_re[16], c_im[16];  // raw != 0: part[k] holds int2 sums, scaled here exactly as the kernels' emission does
     int raw;
     int n_parts;
     float2 *out;
@@ -498,15 +498,12 @@ __global__ __launch_bounds__(256) void k_mfma_combine(CombineArgs a)
         d.x = __dadd_rn(v.x, d.x);
         d.y = __dadd_rn(v.y, d.y);
     }
-    float cf = 1.f, sf = 0.f;
+    double cs = 1.0, sn = 0.0;
     if (a.rotate) {
         const unsigned long long ph = a.rot_base + static_cast<unsigned long long>(a.m_first + i) * a.rot_step;
-        double sn, cs;
         sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &sn, &cs);
-        cf = static_cast<float>(cs);
-        sf = static_cast<float>(sn);
     }
-    a.out[i] = mfma_finish(d.x, d.y, a.conj_sum, a.rotate, cf, sf, a.sc_re, a.sc_im);
+    a.out[i] = mfma_finish(d.x, d.y, a.conj_sum, a.rotate, cs, sn, a.sc_re, a.sc_im);
 }
 }  // namespace iqa
 
@@ -514,7 +511,7 @@ extern "C" int iqa_mfma_combine(const iqa_chan_params *p, const void *const *par
                                 const double *raw_scale, int64_t m_first, int64_t n_out, void *z_out_dev, void *stream)
 {
     if (p == nullptr || partials_dev == nullptr) return fail_inval("params is NULL");
-    if (n_partials < 1 || n_partials > 8) return fail_inval("1..8 partial buffers");
+    if (n_partials < 1 || n_partials > 16) return fail_inval("1..16 partial buffers");
     if (n_out < 0 || m_first < 0) return fail_inval("negative size");
     if (n_out == 0) return IQA_OK;
     if (!z_out_dev) return fail_inval("NULL device pointer");

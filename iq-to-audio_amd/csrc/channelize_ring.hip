@@ -265,8 +265,7 @@ __device__ __forceinline__ void ring_emit_store(const MfmaArgs &a, const RingCtx
             else
                 a.partial_out[c.i0 + i] = make_double2(d_re, d_im);
         } else {
-            a.out[c.i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, static_cast<float>(e.wc), static_cast<float>(e.ws),
-                                          a.sc_re, a.sc_im);
+            a.out[c.i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, e.wc, e.ws, a.sc_re, a.sc_im);
         }
     }
     const double nc = e.wc * a.rot64_re - e.ws * a.rot64_im;
@@ -933,13 +932,17 @@ static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_
     }
 }
 
-// The pacing words of the lane-pair launches (RG_PACE_WORDS x 4 bytes per device, allocated and cleared at the first pair
-// launch on that device -- not inside a stream capture -- and never freed: library state, see the header's conventions).
-// Entries carry the launch's token, so nothing is reset between launches.
-static unsigned int *ring_pace_buffer(unsigned int &token)
+// The pacing words of the lane-pair launches: RG_PACE_WORDS x 4 bytes per device, library state (see the header's
+// conventions), never freed.  Allocated and cleared -- synchronously -- at the first pair launch on a device that is
+// NOT inside a stream capture (an allocation would invalidate the capture: such a launch runs unpaced, which is correct,
+// only its workgroups may drift apart); every launch takes its own slice of the buffer, handed out round-robin, so two
+// pair launches in flight on one device do not share words, and entries carry the launch's token, so nothing is reset
+// between launches.
+static unsigned int *ring_pace_buffer(unsigned int &token, int words, hipStream_t stream)
 {
     static std::mutex mu;
     static unsigned int *buf[64] = {};
+    static int next_off[64] = {};
     static unsigned int next_token = 1;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -947,14 +950,29 @@ static unsigned int *ring_pace_buffer(unsigned int &token)
     token = next_token = (next_token % 0xFFFFFu) + 1;
     unsigned int *&b = buf[dev & 63];
     if (b == nullptr) {
-        void *p = nullptr;
-        if (hipMalloc(&p, RG_PACE_WORDS * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, RG_PACE_WORDS * sizeof(unsigned int)) != hipSuccess) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
             (void)hipGetLastError();
-            return nullptr;  // (the launch runs unpaced: correct, only its workgroups may drift apart)
+            return nullptr;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, RG_PACE_WORDS * sizeof(unsigned int)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemset(p, 0, RG_PACE_WORDS * sizeof(unsigned int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
         }
         b = static_cast<unsigned int *>(p);
     }
-    return b;
+    if (words > RG_PACE_WORDS) return nullptr;
+    int &off = next_off[dev & 63];
+    if (off + words > RG_PACE_WORDS) off = 0;
+    unsigned int *mine = b + off;
+    off += (words + 63) & ~63;
+    return mine;
 }
 
 bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8)
@@ -1123,7 +1141,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
     if (blocks_out) *blocks_out = blocks;
     if (pairs) {
         m.c.pace = nullptr;
-        if (groups * 8 * (n_lanes / 2) <= RG_PACE_WORDS) m.c.pace = ring_pace_buffer(m.c.pace_token);
+        m.c.pace = ring_pace_buffer(m.c.pace_token, static_cast<int>(std::min<long long>(groups * 8 * (n_lanes / 2), RG_PACE_WORDS + 1)), stream);
         switch (a.ksteps) {
 #define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream)
             RG_PAIRS(9); RG_PAIRS(10); RG_PAIRS(11); RG_PAIRS(12); RG_PAIRS(13); RG_PAIRS(14); RG_PAIRS(16);

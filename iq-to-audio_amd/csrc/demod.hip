@@ -272,6 +272,58 @@ __global__ __launch_bounds__(1024) void k_mean_power_small(const float2 *z, long
     }
 }
 
+// Wideband level of raw capture frames (the precision guard's reference level, reference has no counterpart: its
+// channel filter runs in complex128 and has no level dependence, processing.py:300-346): mean square of the VALUES
+// (I and Q alike; uint8 minus 128), estimated from up to 1024 x `rounds` 16-byte vectors spread evenly over the range.
+// One workgroup, fixed order, the result WRITTEN (mapped pinned host memory is fine).
+template <int FMT>
+__global__ __launch_bounds__(1024) void k_raw_level(const uint4 *raw, long long n_vec, long long step, int rounds, double *out)
+{
+    __shared__ double s_w[16];
+    double acc = 0.0;
+    long long cnt = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const long long i = (static_cast<long long>(r) * 1024 + threadIdx.x) * step;
+        if (i >= n_vec) break;
+        const uint4 v = raw[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (FMT == IQA_FMT_S16) {
+                const float a = static_cast<float>(static_cast<short>(w[k] & 0xFFFF)), b = static_cast<float>(static_cast<short>(w[k] >> 16));
+                acc += static_cast<double>(a * a + b * b);
+            } else if (FMT == IQA_FMT_U8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = static_cast<float>(static_cast<int>((w[k] >> (8 * j)) & 0xFF) - 128);
+                    acc += static_cast<double>(a * a);
+                }
+            } else {
+                const float a = __uint_as_float(w[k]);
+                acc += static_cast<double>(a) * static_cast<double>(a);
+            }
+        }
+        cnt += FMT == IQA_FMT_S16 ? 8 : FMT == IQA_FMT_U8 ? 16 : 4;
+    }
+    acc = wave_sum(acc);
+    double c = wave_sum(static_cast<double>(cnt));
+    __shared__ double s_c[16];
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = acc;
+        s_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, n = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            t += s_w[w];
+            n += s_c[w];
+        }
+        out[0] = n > 0.0 ? t / n : 0.0;
+    }
+}
+
 // AudioWriter.write: running pre-clip peak, clip, per-segment sum of squares (float64).
 // One float64 atomic per block when the block lies inside one segment (the common case: a
 // reference chunk is >= 40k channel-rate samples); per-thread flushes only for blocks that
@@ -837,6 +889,26 @@ extern "C" int iqa_mean_power_batch(const void *z_dev, int64_t n_each, int32_t p
         if (rc != IQA_OK) return rc;
     }
     return IQA_OK;
+}
+
+extern "C" int iqa_raw_level(int32_t fmt, const void *raw_dev, int64_t n_values, void *mean_square_out, void *stream)
+{
+    if (fmt != IQA_FMT_S16 && fmt != IQA_FMT_U8 && fmt != IQA_FMT_F32) return fail_inval("bad sample format");
+    if (n_values < 0) return fail_inval("negative length");
+    if (!mean_square_out) return fail_inval("NULL output pointer");
+    const int per_vec = fmt == IQA_FMT_S16 ? 8 : fmt == IQA_FMT_U8 ? 16 : 4;
+    const long long n_vec = n_values / per_vec;
+    if (n_vec > 0 && !raw_dev) return fail_inval("NULL device pointer");
+    if (n_vec > 0 && (reinterpret_cast<uintptr_t>(raw_dev) & 15)) return fail_inval("raw frames must be 16-byte aligned");
+    constexpr int ROUNDS = 8;  // up to 8192 vectors = 65536 int16 values: 0.4 % relative standard error on noise
+    const long long step = std::max<long long>(1, n_vec / (1024LL * ROUNDS));
+    hipStream_t s = as_stream(stream);
+    double *out = static_cast<double *>(mean_square_out);
+    const uint4 *raw = static_cast<const uint4 *>(raw_dev);
+    if (fmt == IQA_FMT_S16) hipLaunchKernelGGL(k_raw_level<IQA_FMT_S16>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, ROUNDS, out);
+    else if (fmt == IQA_FMT_U8) hipLaunchKernelGGL(k_raw_level<IQA_FMT_U8>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, ROUNDS, out);
+    else hipLaunchKernelGGL(k_raw_level<IQA_FMT_F32>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, ROUNDS, out);
+    return check_launch("k_raw_level");
 }
 
 extern "C" int iqa_writer_clip(const void *a_dev, int64_t n, void *peak_dev, const void *seg_starts_dev,

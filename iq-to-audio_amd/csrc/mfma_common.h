@@ -53,18 +53,22 @@ __device__ __forceinline__ double mfma_scaled_sum(double v, double c, double uni
 {
     return __dmul_rn(__fma_rn(v, 256.0, c), unit);
 }
-__device__ __forceinline__ float2 mfma_finish(double d_re, double d_im, int conj_sum, int rotate, float cf, float sf, float sc_re,
+// conjugation, rotation and ingest-order scaling in FLOAT64, ONE rounding to float32 at the very end: with the "full"
+// precision's sums (error ~1e-9 of full scale) z then carries the same float32 rounding as the reference's own
+// complex128 -> complex64 cast (processing.py:339) on all but a few per cent of the samples; rotating in float32 after an
+// early cast left ~4e-8 RMS (three roundings at |z| ~ 0.7), which the reference's SSB AGC amplifies (decoders/ssb.py:75-77).
+__device__ __forceinline__ float2 mfma_finish(double d_re, double d_im, int conj_sum, int rotate, double cw, double sw, float sc_re,
                                               float sc_im)
 {
-    const float my_re = static_cast<float>(d_re);
-    float my_im = static_cast<float>(d_im);
-    if (conj_sum) my_im = -my_im;
-    float yr = my_re, yi = my_im;
+    if (conj_sum) d_im = -d_im;
+    double yr = d_re, yi = d_im;
     if (rotate) {
-        yr = __fmaf_rn(my_re, cf, -__fmul_rn(my_im, sf));
-        yi = __fmaf_rn(my_re, sf, __fmul_rn(my_im, cf));
+        yr = __fma_rn(d_re, cw, -__dmul_rn(d_im, sw));
+        yi = __fma_rn(d_re, sw, __dmul_rn(d_im, cw));
     }
-    return make_float2(__fmaf_rn(yr, sc_re, -__fmul_rn(yi, sc_im)), __fmaf_rn(yr, sc_im, __fmul_rn(yi, sc_re)));
+    // (out_scale is one of 1, j, -j: exact)
+    const double sr = static_cast<double>(sc_re), si = static_cast<double>(sc_im);
+    return make_float2(static_cast<float>(__fma_rn(yr, sr, -__dmul_rn(yi, si))), static_cast<float>(__fma_rn(yr, si, __dmul_rn(yi, sr))));
 }
 
 // emission shared by both kernels: output m0+i sits at position 64+i of the S1/S2 arrays
@@ -87,17 +91,14 @@ __device__ __forceinline__ void mfma_emit(const MfmaArgs &a, const int *s_acc, i
             a.partial_out[i0 + i] = make_double2(d_re, d_im);
             continue;
         }
-        float cf = 1.f, sf = 0.f;
+        double cw = 1.0, sw = 0.0;
         if (a.rotate) {
             const unsigned long long m = static_cast<unsigned long long>(m0 + i);
             const unsigned long long ph = a.rot_base + m * a.rot_step;
             const double frac = static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0);
-            double s, c;
-            sincospi(2.0 * frac, &s, &c);
-            cf = static_cast<float>(c);
-            sf = static_cast<float>(s);
+            sincospi(2.0 * frac, &sw, &cw);
         }
-        a.out[i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, cf, sf, a.sc_re, a.sc_im);
+        a.out[i0 + i] = mfma_finish(d_re, d_im, a.conj_sum, a.rotate, cw, sw, a.sc_re, a.sc_im);
     }
 }
 

@@ -170,16 +170,19 @@ MFMA_MAX_KSTEPS_PER_PASS = 16  # 128 KiB of fragments leaves room for >= 1888 ou
 
 @dataclass
 class MfmaGroup:
-    """Tap rows 64*g+1 .. 64*g+64 of the filter, quantised on their own scale."""
+    """Tap rows 64*q+1 .. 64*q+64 of the filter (or, ``residual``, what an earlier group left of them), quantised on
+    their own scale."""
 
     afrag: np.ndarray  # int8 [ksteps, 4, 2, 64, 16] tap fragments in MFMA lane order
     unit: float  # value of one tap LSB
     tq: np.ndarray  # int32 [128, Kpad] quantised taps T = 256*q1 + q2
+    q: int = 0  # tap-row group (the data rows a lane of this group streams start 64*q rows earlier)
+    residual: bool = False  # the taps of this group are the quantisation residue of the group in front of it
 
 
 @dataclass
 class MfmaPass:
-    group: int
+    group: int  # index into MfmaPlan.groups
     k_first: int
     k_count: int
     c_re: float  # 128 * sum(T) over the real-output rows and this pass's k range (low-byte bias)
@@ -194,6 +197,9 @@ class MfmaPlan:
     groups: list
     passes: list
     err_norm: float = 0.0  # sqrt(sum_k |T_k u - g_k|^2) per unit of full scale: the z error for a white input of unit RMS
+    #: RMS of the part of the z error that does NOT scale with the input: the q2*lo' products the int16 kernels drop
+    #: (low tap byte x low data byte), for data whose low bytes are uniform (any capture well above 8 bits)
+    floor_rms: float = 0.0
 
     # single-pass conveniences (tests, and the common ceil(L/D) <= 64, D <= 256 case)
     @property
@@ -215,6 +221,10 @@ class MfmaPlan:
     @property
     def c_im(self):
         return sum(p.c_im for p in self.passes if p.group == 0)
+
+    def z_error_rms(self, wideband_rms: float) -> float:
+        """Expected RMS error of z for a capture of the given wideband RMS (fraction of full scale)."""
+        return math.hypot(self.err_norm * wideband_rms, self.floor_rms)
 
 
 def mfma_supported(plan: ChannelPlan) -> bool:
@@ -239,7 +249,39 @@ def _mfma_layout(ntaps: int, decimation: int, group: int):
     return ksteps, kc, ok, flat
 
 
-def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = None) -> MfmaPlan:
+_LOW_BYTE_VAR = (256.0 * 256.0 - 1.0) / 12.0  # variance of a uniform low data byte lo' in [-128, 127]
+
+
+def _quantise_rows(a: np.ndarray, acc32: bool, high_byte_only: bool, col_ranges=None):
+    """(unit, T, q1, q2) for one 128-row tap matrix: T = rint(a / unit) = 256*q1 + q2 with both bytes signed,
+    unit = max|a| / 32639 -- enlarged, with ``acc32``, until 256*S1 + S2 of a component cannot overflow an int32
+    for ANY int16 input (``col_ranges``: the column ranges that are summed into one int32 -- a pass of the kernel covers
+    one k-step range and hands its sum on in float64).  ``high_byte_only``: q2 = 0 (T a multiple of 256): the int16
+    kernels then drop nothing -- their q2*lo' term is identically zero -- at the price of taps of ~6 bits."""
+    amax = float(np.abs(a).max())
+    unit = amax / 32639.0 if amax > 0 else 1.0
+    while True:
+        if high_byte_only:
+            q1 = np.clip(np.rint(a * (1.0 / (256.0 * unit))), -127, 127).astype(np.int32)
+            q2 = np.zeros_like(q1)
+            t = q1 << 8
+        else:
+            t = np.rint(a * (1.0 / unit)).astype(np.int32)
+            q2 = ((t + 128) & 255) - 128
+            q1 = (t - q2) >> 8
+        if not acc32:
+            break
+        # |256*S1 + S2| <= sum 128*(257|q1| + |q2|) over one component's rows (|hi|, |lo'| <= 128)
+        w = 128 * (257 * np.abs(q1).astype(np.int64) + np.abs(q2))
+        bound = max(int(w[r, c0:c1].sum()) for r in (slice(0, MFMA_Q), slice(MFMA_Q, 2 * MFMA_Q))
+                    for c0, c1 in (col_ranges or [(0, a.shape[1])]))
+        if bound < 2**31 - 1:
+            break
+        unit *= max(1.02, bound / (2**31 - 1) * 1.001)
+    return unit, t, q1, q2
+
+
+def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = None, residual: bool = False) -> MfmaPlan:
     """Quantise the (already NCO-rotated, scaled) taps to 16-bit fixed point and lay them out as
     the A operand of v_mfma_i32_32x32x32_i8.
 
@@ -247,6 +289,14 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
     enlarged (taps of ~14 bits for the standard 12.5 kHz filters) until
     sum_k 128*(257|q1_k| + |q2_k|) < 2^31 over the rows of a component, so that the sum cannot overflow for
     ANY int16 input; everything stays exact integer arithmetic.
+
+    ``residual`` (the "fine" precision of the pipeline): every tap-row group becomes TWO groups that stream the same data
+    rows -- the taps themselves and what their quantisation left over, quantised again on a unit of its own (~1/20 of
+    the first one's LSB under the int32 bound) -- whose partial sums ``iqa_mfma_combine`` adds.  For int16 captures the
+    first of the two keeps the high tap byte only: the kernels drop the (low tap byte) x (low data byte) products, an
+    error of the same size as the tap rounding itself, and with q2 = 0 there is nothing to drop; its result is then the
+    EXACT product of its (coarse) taps and the residual group carries everything else.  Twice the matrix work, ~20x
+    less error, same kernels.
 
     Rows: row = comp*64 + (q-1) within a q-group of 64 tap rows; columns kap = 2*rho + c over one
     data row of D frames:
@@ -263,10 +313,11 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
     D = plan.decimation
     n_groups = max(1, -(-(-(-plan.ntaps // D)) // MFMA_Q))
     groups, passes = [], []
-    err_sq = 0.0
+    err_sq = floor_sq = 0.0
     ksteps = -(-2 * D // 32)
     n_chunks = -(-ksteps // (max_ksteps or MFMA_MAX_KSTEPS_PER_PASS))  # k-step ranges: one pass each
     bounds = [round(i * ksteps / n_chunks) for i in range(n_chunks + 1)]
+    s16 = plan.fmt == "s16"
     for gi in range(n_groups):
         _, kc, ok, flat = _mfma_layout(plan.ntaps, D, gi)
         kpad = 32 * ksteps
@@ -278,33 +329,27 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
         a[:MFMA_Q, 1 : 2 * D : 2] = -gim
         a[MFMA_Q:, 0 : 2 * D : 2] = gim
         a[MFMA_Q:, 1 : 2 * D : 2] = gre
-        amax = float(np.abs(a).max())
-        unit = amax / 32639.0 if amax > 0 else 1.0
-        while True:
-            t = np.rint(a * (1.0 / unit)).astype(np.int32)
-            q2 = ((t + 128) & 255) - 128
-            q1 = (t - q2) >> 8
-            if not acc32:
-                break
-            # |256*S1 + S2| <= sum 128*(257|q1| + |q2|) over one component's rows (|hi|, |lo'| <= 128)
-            bound = max(int((128 * (257 * np.abs(q1[r]).astype(np.int64) + np.abs(q2[r]))).sum())
-                        for r in (slice(0, MFMA_Q), slice(MFMA_Q, 2 * MFMA_Q)))
-            if bound < 2**31 - 1:
-                break
-            unit *= max(1.02, bound / (2**31 - 1) * 1.001)
-        err_sq += 0.5 * float(((t * unit - a) ** 2).sum())  # every complex tap sits in the matrix twice (re and im rows)
-        frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
-        frag[:, :, 0] = q1.reshape(-1)[flat]
-        frag[:, :, 1] = q2.reshape(-1)[flat]
-        groups.append(MfmaGroup(frag, unit, t))
-        for ci in range(n_chunks):
-            k0, k1 = bounds[ci], bounds[ci + 1]
-            sl = t[:, 32 * k0 : 32 * k1]
-            # int16 data are split v = 256*hi + lo' + 128: the 128 makes a constant 128*sum(T); uint8 data have one piece
-            bias = 128.0 if plan.fmt == "s16" else 0.0
-            passes.append(MfmaPass(gi, k0, k1 - k0, bias * float(sl[:MFMA_Q].sum(dtype=np.int64)),
-                                   bias * float(sl[MFMA_Q:].sum(dtype=np.int64))))
-    return MfmaPlan(ksteps, groups, passes, math.sqrt(err_sq) / INGEST_SCALE[plan.fmt])
+        left = a
+        for part in range(2 if residual else 1):
+            # (uint8 data are one piece: the kernels' T*v is exact whatever the low tap byte holds)
+            unit, t, q1, q2 = _quantise_rows(left, acc32, high_byte_only=residual and part == 0 and s16,
+                                             col_ranges=[(32 * bounds[i], 32 * bounds[i + 1]) for i in range(n_chunks)])
+            left = left - t * unit
+            if s16:
+                floor_sq += unit * unit * _LOW_BYTE_VAR * float((q2.astype(np.float64) ** 2).sum())
+            frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
+            frag[:, :, 0] = q1.reshape(-1)[flat]
+            frag[:, :, 1] = q2.reshape(-1)[flat]
+            groups.append(MfmaGroup(frag, unit, t, q=gi, residual=part == 1))
+            for ci in range(n_chunks):
+                k0, k1 = bounds[ci], bounds[ci + 1]
+                sl = t[:, 32 * k0 : 32 * k1]
+                # int16 data are split v = 256*hi + lo' + 128: the 128 makes a constant 128*sum(T); uint8 data have one piece
+                bias = 128.0 if s16 else 0.0
+                passes.append(MfmaPass(len(groups) - 1, k0, k1 - k0, bias * float(sl[:MFMA_Q].sum(dtype=np.int64)),
+                                       bias * float(sl[MFMA_Q:].sum(dtype=np.int64))))
+        err_sq += 0.5 * float((left**2).sum())  # every complex tap sits in the matrix twice (re and im rows)
+    return MfmaPlan(ksteps, groups, passes, math.sqrt(err_sq) / INGEST_SCALE[plan.fmt], math.sqrt(floor_sq))
 
 
 def mfma_interior(consumed: int, n_frames: int, m_first: int, n_out: int, decimation: int, ksteps: int,

@@ -163,9 +163,30 @@ class _ChannelKernel:
     _VARIANT = {"plain": (0, 0), "ring": (64, 0)}  # flags, extra LDS bytes
     mfma_min_outputs = 32768
 
-    def __init__(self, plan: P.ChannelPlan, exact: bool = False):
+    #: Precisions of a channelizer, cheapest first:
+    #:   "fast"    -- the ring kernels, ONE int32 sum per output component, ~14-bit taps: z error ~3e-6 of full scale
+    #:   "fine"    -- the same kernels, every tap-row group as TWO lanes (high-byte-only taps + their residue, added by
+    #:                iqa_mfma_combine): twice the matrix work, error 10..90x smaller; uint8 captures: exact products
+    #:   "full"    -- the per-lane kernel (separate S1/S2 sums, no int32 bound: 16-bit taps) with the same two groups as
+    #:                chained passes: z error ~1e-9 of full scale -- below the float32 rounding of z itself -- at ~2.5x the
+    #:                time of "fast" (int16 captures; uint8 -> "fine", float32 -> "float32")
+    #:   "float32" -- the float32 VALU kernel for every output (~20x the time of "fast"; the only form for float32 captures)
+    PRECISIONS = ("fast", "fine", "full", "float32")
+
+    def __init__(self, plan: P.ChannelPlan, exact: bool = False, precision: str | None = None):
         self.plan = plan
-        self.exact = bool(exact)  # float32 kernel everywhere (the precision guard's choice for very weak channels)
+        precision = precision or ("float32" if exact else "fast")
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {self.PRECISIONS}, not {precision!r}")
+        if plan.fmt == "f32" and precision != "fast":
+            precision = "float32"
+        if plan.fmt == "u8" and precision == "full":
+            precision = "fine"
+        self.precision = precision
+        self.exact = precision == "float32"  # float32 kernel everywhere
+        self.variant = "plain" if precision == "full" else self.mfma_variant
+        self.acc32 = bool(self.ring_acc32) and precision != "full"
+        self.residual = precision in ("fine", "full")
         lpad = int(N.lib().iqa_taps_padded_len(plan.ntaps))
         if plan.taps_window.size != lpad:
             raise ValueError("tap window padding does not match the library")
@@ -184,8 +205,8 @@ class _ChannelKernel:
         # the per-lane kernel (int16) or the VALU kernel (uint8)
         ks_all = -(-2 * plan.decimation // 32)
         self._ring_mode = 0
-        if plan.fmt in ("s16", "u8") and self.mfma_variant == "ring":
-            acc32, code = int(bool(self.ring_acc32)), P.FMT_CODE[plan.fmt]
+        if plan.fmt in ("s16", "u8") and self.variant == "ring":
+            acc32, code = int(bool(self.acc32)), P.FMT_CODE[plan.fmt]
             self._ring_mode = int(N.lib().iqa_mfma_ring_mode(code, plan.decimation, 0, ks_all, acc32))
             if self._ring_mode == 0:
                 self._ring_mode = int(N.lib().iqa_mfma_ring_mode(code, plan.decimation, 0, min(ks_all, self.RING_ROWS_KSTEPS), acc32))
@@ -197,15 +218,15 @@ class _ChannelKernel:
 
     def _ensure_mfma_locked(self):
         if self.mfma is None:
-            ring = self.mfma_variant == "ring" and self._ring_mode != 0
-            mp = P.plan_mfma(self.plan, acc32=ring and self.ring_acc32,
-                             max_ksteps=self.RING_ROWS_KSTEPS if self._ring_mode == 2 else None)
+            ring = self.variant == "ring" and self._ring_mode != 0
+            mp = P.plan_mfma(self.plan, acc32=ring and self.acc32,
+                             max_ksteps=self.RING_ROWS_KSTEPS if self._ring_mode == 2 else None, residual=self.residual)
             self.mfma = mp
             self.afrag_dev = [D.from_numpy(g.afrag.reshape(-1).view(np.uint8)) for g in mp.groups]
             self.mfma_params = []
             for ps in mp.passes:
                 # one 8-wave block per CU owns all 160 KiB of LDS: this pass's tap fragments + 16 B per output
-                variant = self.mfma_variant
+                variant = self.variant
                 if variant == "ring" and not ring:
                     variant = "plain"
                 if self._range_max(ps.k_count, variant) < 512:  # the staging ring does not fit LDS next to the taps
@@ -213,8 +234,8 @@ class _ChannelKernel:
                 rng = self._range_max(ps.k_count, variant)
                 self._pass_variant = getattr(self, "_pass_variant", []) + [variant]
                 self.mfma_params.append(N.MfmaParams(
-                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.ring_acc32) else 0), unit=mp.groups[ps.group].unit / (256.0 if self.plan.fmt == "u8" else 1.0), c_re=ps.c_re,
-                    c_im=ps.c_im, debug_stamps=None, q_group=ps.group, k_first=ps.k_first, k_count=ps.k_count,
+                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.acc32) else 0), unit=mp.groups[ps.group].unit / (256.0 if self.plan.fmt == "u8" else 1.0), c_re=ps.c_re,
+                    c_im=ps.c_im, debug_stamps=None, q_group=mp.groups[ps.group].q, k_first=ps.k_first, k_count=ps.k_count,
                     finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
 
@@ -222,6 +243,12 @@ class _ChannelKernel:
         """z error (RMS) of the fixed-point kernels per unit RMS of a white wideband input at full scale = 1: the 2-norm
         of the tap quantisation error (0.0 when this channel never runs on the matrix cores)."""
         return float(self._ensure_mfma().err_norm) if self._mfma_ok else 0.0
+
+    def fixed_point_error_rms(self, wideband_rms: float) -> float:
+        """Expected z error (RMS, fraction of full scale) of this kernel for a capture of the given wideband RMS: tap
+        rounding x wideband level plus the level-independent floor of the dropped (low tap byte) x (low data byte)
+        products (0.0 when this channel never runs on the matrix cores)."""
+        return float(self._ensure_mfma().z_error_rms(wideband_rms)) if self._mfma_ok else 0.0
 
     def _range_max(self, k_count: int, variant: str) -> int:
         if variant == "ring":  # tap fragments in registers, sums in a sliding window: a block is not bounded by LDS
@@ -247,7 +274,7 @@ class _ChannelKernel:
         if variant != "ring":
             return 1
         lds = int(N.lib().iqa_mfma_ring_lds_bytes(P.FMT_CODE[self.plan.fmt], self.plan.decimation, ps.k_first, ps.k_count,
-                                                  1 if self.ring_acc32 else 0))
+                                                  1 if self.acc32 else 0))
         return 2 if 0 < lds <= 80 * 1024 else 1
 
     def _valu(self, raw_dev, n_frames, consumed, hist_dev, m_first, n_out, out_dev):
@@ -274,7 +301,7 @@ class _ChannelKernel:
         ksteps = -(-2 * d // 32)
         n_groups = max(1, -(-(-(-self.plan.ntaps // d)) // P.MFMA_Q))
         m_a, m_b = P.mfma_interior(consumed, n_frames, m_first, n_out, d, ksteps, n_groups)
-        if self.mfma_variant == "ring" and self._ring_mode == 1:
+        if self.variant == "ring" and self._ring_mode == 1:
             # a contiguous ring tile is fetched as 2048*ksteps bytes from its first frame
             m_b = min(m_b, (n_frames + consumed - 512 * ksteps - 1) // d + 2)
         return (m_a, m_b) if m_b > m_a else (m_first, m_first)
@@ -304,7 +331,7 @@ class _ChannelKernel:
         filter's transient and read a snippet of a longer buffer).  False (nothing launched) when the range is not
         wholly interior or the capture format has no matrix-core kernel."""
         with self._lock:
-            if not (self._mfma_ok and self.mfma_variant == "ring" and self._ring_mode) or n_out < 64:
+            if not (self._mfma_ok and self.variant == "ring" and self._ring_mode) or n_out < 64:
                 return False
             m_a, m_b = self._interior(0, n_frames, m_first, n_out)
             if m_a != m_first or m_b != m_first + n_out:
@@ -384,13 +411,13 @@ def immutable_taps(taps) -> np.ndarray:
 
 
 def _cached_kernel(taps: np.ndarray, *, sample_rate: float, freq_offset: float, mix_sign: int, decimation: int,
-                   fmt: str, iq_order: str, exact: bool = False):
+                   fmt: str, iq_order: str, exact: bool = False, precision: str | None = None):
     """(plan, kernel) for this configuration, planned once per process and device."""
     taps = np.ascontiguousarray(taps)
     raw, raw_hash = _taps_fingerprint(taps)
     key = (raw_hash, taps.dtype.str, taps.shape, float(sample_rate), float(freq_offset), int(mix_sign), int(decimation),
-           fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, _ChannelKernel.ring_acc32, bool(exact),
-           D.torch_mod().cuda.current_device())
+           fmt, iq_order, _ChannelKernel.use_mfma, _ChannelKernel.mfma_variant, _ChannelKernel.ring_acc32,
+           precision or ("float32" if exact else "fast"), D.torch_mod().cuda.current_device())
     with _KERNEL_CACHE_LOCK:
         hit = _KERNEL_CACHE.get(key)
         if hit is not None and (hit[0] is raw or hit[0] == raw):
@@ -399,7 +426,7 @@ def _cached_kernel(taps: np.ndarray, *, sample_rate: float, freq_offset: float, 
     lpad = int(N.lib().iqa_taps_padded_len(len(taps)))
     plan = P.plan_channel(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
                           decimation=decimation, fmt=fmt, iq_order=iq_order, padded_len=lpad)
-    kernel = _ChannelKernel(plan, exact)
+    kernel = _ChannelKernel(plan, exact, precision)
     with _KERNEL_CACHE_LOCK:
         _KERNEL_CACHE[key] = (raw, plan, kernel)
         while len(_KERNEL_CACHE) > _KERNEL_CACHE_MAX:
@@ -494,11 +521,12 @@ class Channelizer:
     """
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, mix_sign: int, decimation: int,
-                 fmt: str = "s16", iq_order: str = "iq", exact: bool = False):
-        """``exact``: the float32 kernel for every output (no fixed-point matrix-core kernel): ~20x slower, error ~1e-8
-        of full scale instead of ~1e-6 .. 1e-5 -- what the pipeline's precision guard picks for very weak channels."""
-        self.plan, self._kernel = _cached_kernel(taps, sample_rate=sample_rate, freq_offset=freq_offset,
-                                                 mix_sign=mix_sign, decimation=decimation, fmt=fmt, iq_order=iq_order, exact=exact)
+                 fmt: str = "s16", iq_order: str = "iq", exact: bool = False, precision: str | None = None):
+        """``precision``: "fast" (default), "fine", "full" or "float32" -- see ``_ChannelKernel.PRECISIONS``; what the
+        pipeline's precision guard and its SSB-with-AGC rule pick per target.  ``exact=True`` is "float32"."""
+        self.plan, self._kernel = _cached_kernel(taps, sample_rate=sample_rate, freq_offset=freq_offset, mix_sign=mix_sign,
+                                                 decimation=decimation, fmt=fmt, iq_order=iq_order, exact=exact, precision=precision)
+        self.precision = self._kernel.precision
         self.fmt = fmt
         self.decimation = int(decimation)
         self.ntaps = len(taps)
@@ -547,7 +575,7 @@ class Channelizer:
 
     def _several_lanes(self) -> bool:
         k = self._kernel
-        if not (self.lanes_for_groups and self.fmt in ("s16", "u8") and k._mfma_ok and k.mfma_variant == "ring" and k._ring_mode and k.ring_acc32):
+        if not (self.lanes_for_groups and self.fmt in ("s16", "u8") and k._mfma_ok and k.variant == "ring" and k._ring_mode and k.acc32):
             return False
         return len(k._ensure_mfma().groups) > 1
 
@@ -592,9 +620,14 @@ class ChannelBank:
                 raise ValueError("the channels of a bank share the capture: same sample format, decimation and position")
         self.last_launch = None  # {"lanes": n, "launches": n, "combines": n} of the most recent block (None: one by one)
 
+    @staticmethod
+    def _lane_capable(k) -> bool:
+        """This channel's tap-row groups can be lanes of a shared-ingest launch (ring kernels, int32 sums)."""
+        return bool(k._mfma_ok and k.variant == "ring" and k._ring_mode and k.acc32)
+
     def _shared_shape(self) -> bool:
         ks = [c._kernel for c in self.chans]
-        if not ks or not all(k._mfma_ok and k.mfma_variant == "ring" and k._ring_mode and k.ring_acc32 for k in ks):
+        if not ks or not all(self._lane_capable(k) for k in ks):
             return False
         if len(ks) == 1:  # one channel: worth a shared-ingest launch only when its filter is several lanes (tap-row groups)
             return len(ks[0]._ensure_mfma().groups) > 1
@@ -614,6 +647,20 @@ class ChannelBank:
             zs = self._run_shared(x, n, m_first, n_out, outs, halo, edge_stream)
         if zs is None:
             self.last_launch = None
+            lanes = [i for i, c in enumerate(self.chans) if self._lane_capable(c._kernel)]
+            if 0 < len(lanes) < len(self.chans) and D.is_tensor(raw):
+                # channels of other precisions ("full": chained passes of the per-lane kernel; "float32") in the bank: the
+                # lane-capable ones still share their pass, the others follow one by one
+                sub = ChannelBank([self.chans[i] for i in lanes])
+                got = sub.process(raw, outs=[outs[i] for i in lanes], last_block=last_block, halo=halo, edge_stream=edge_stream)
+                self.last_launch = sub.last_launch
+                res = [None] * len(self.chans)
+                for i, z in zip(lanes, got):
+                    res[i] = z
+                for i, (c, o) in enumerate(zip(self.chans, outs)):
+                    if res[i] is None:
+                        res[i] = c.process(raw, out_dev=o, last_block=last_block, halo=halo)
+                return res
             return [c.process(raw, out_dev=o, last_block=last_block, halo=halo) for c, o in zip(self.chans, outs)]
         for c in self.chans:
             c._advance(x, n, last_block)
@@ -649,7 +696,7 @@ class ChannelBank:
             lane.c_re, lane.c_im = ps.c_re, ps.c_im
             lane.rot_step, lane.rot_base = k.params.rot_step, k.params.rot_base
             lane.out_scale_re, lane.out_scale_im = k.params.out_scale_re, k.params.out_scale_im
-            lane.q_group, lane.finalize = 0, 1
+            lane.q_group, lane.finalize = mp.groups[0].q, 1
             lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
             lane.raw_partials = 0
             k.last_kernel = ("k_channelize_mfma_u8" if self.fmt == "u8" else "k_channelize_mfma_s16") + "_ring"
@@ -717,7 +764,7 @@ class ChannelBank:
                     lane.c_re, lane.c_im = ps.c_re, ps.c_im
                     lane.rot_step, lane.rot_base = k.params.rot_step, k.params.rot_base
                     lane.out_scale_re, lane.out_scale_im = k.params.out_scale_re, k.params.out_scale_im
-                    lane.q_group, lane.finalize = gi, int(fin)
+                    lane.q_group, lane.finalize = mp.groups[gi].q, int(fin)
                     lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
                     lane.raw_partials = int(raw and not fin)
                 N.call(entry, c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first), c_int32(k_count), c_int32(rng),
@@ -731,7 +778,7 @@ class ChannelBank:
         # by two; an odd lane out shares its workgroup with nobody (None).  ONE launch either way: the capture crosses
         # HBM once.
         if self.pair_lanes and len(kranges) == 1 and N.lib().iqa_mfma_ring_pairs(P.FMT_CODE[self.fmt], self.decimation, *kranges[0]):
-            paired = sorted(ids, key=lambda i: -i[1])
+            paired = sorted(ids, key=lambda i: -plans[i[0]].groups[i[1]].q)
             if len(paired) & 1:
                 paired.append(None)
             for lo in range(0, len(paired), self.MAX_LANES):
@@ -814,20 +861,24 @@ def probe_targets(warmup, sample_rate: float, specs: list, decimation: int, *, f
     if not ChannelBank(chans).run_interior_only(x_all, n_in, discard, keep, [z_keep[i * keep : (i + 1) * keep] for i in range(len(chans))]):
         return None
     N.call("iqa_mean_power_batch", N.ptr(z_keep), c_int64(keep), c_int32(len(chans)), c_int64(0), N.ptr(host), N.stream_ptr())
+    level_slot = None
+    if host.numel() > 2 * len(specs):  # room for the wideband level of the warm-up block behind the powers
+        level_slot = host[2 * len(specs) : 2 * len(specs) + 1]
+        queue_raw_level(warmup, fmt, level_slot)
     done = D.torch_mod().cuda.Event()
     done.record()
-    return [MixSignProbe.from_powers(host[2 * i : 2 * i + 2], done) for i in range(len(specs))]
+    return [MixSignProbe.from_powers(host[2 * i : 2 * i + 2], done, level_slot, fmt) for i in range(len(specs))]
 
 
 def _mean_power_into(z_dev, skip: int, out_slot) -> None:
     N.call("iqa_mean_power", N.ptr(z_dev), c_int64(z_dev.numel()), c_int64(skip), N.ptr(out_slot), N.stream_ptr())
 
 
-_PINNED_SCALARS: list = []  # [pinned double[2], owner] -- a buffer goes back to the pool when its probe has been read
+_PINNED_SCALARS: list = []  # [pinned double[4], owner] -- a buffer goes back to the pool when its probe has been read
 
 
 def _pinned_scalars(owner):
-    """A reusable pinned double[2] for probe read-backs (pin_memory() is slow: allocate once per slot).  The
+    """A reusable pinned double[4] for probe read-backs (pin_memory() is slow: allocate once per slot).  The
     buffer stays with ``owner`` until ``_release_scalars``: several probes may be in flight at once."""
     torch = D.torch_mod()
     with _KERNEL_CACHE_LOCK:
@@ -835,7 +886,7 @@ def _pinned_scalars(owner):
             if t[1] is None:
                 t[1] = owner
                 return t[0]
-        t = [torch.empty(2, dtype=torch.float64).pin_memory(), owner]
+        t = [torch.zeros(4, dtype=torch.float64).pin_memory(), owner]  # [power(+1), power(-1), raw mean square, spare]
         _PINNED_SCALARS.append(t)
         return t[0]
 
@@ -847,7 +898,7 @@ def reserve_pinned_scalars(count: int) -> None:
     with _KERNEL_CACHE_LOCK:
         free = sum(1 for t in _PINNED_SCALARS if t[1] is None)
         for _ in range(max(0, count - free)):
-            _PINNED_SCALARS.append([torch.empty(2, dtype=torch.float64).pin_memory(), None])
+            _PINNED_SCALARS.append([torch.zeros(4, dtype=torch.float64).pin_memory(), None])
 
 
 def _release_scalars(buf) -> None:
@@ -855,6 +906,59 @@ def _release_scalars(buf) -> None:
         for t in _PINNED_SCALARS:
             if t[0] is buf:
                 t[1] = None
+
+
+def queue_raw_level(warmup, fmt: str, out_slot) -> None:
+    """Queue the wideband-level estimate of raw frames (``iqa_raw_level``: mean square of up to 65536 values spread over
+    ``warmup``) into ``out_slot`` (double[1], device or pinned host memory) on the current stream."""
+    x, n = _as_frames(warmup, fmt)
+    flat = x.view(D.torch_mod().float32) if x.is_complex() else x
+    N.call("iqa_raw_level", c_int32(P.FMT_CODE[fmt]), N.ptr(flat), c_int64(flat.numel()), N.ptr(out_slot), N.stream_ptr())
+
+
+def wideband_rms_from(mean_square: float, fmt: str) -> float:
+    """RMS of the complex samples (fraction of full scale) from the mean square of the raw values."""
+    return math.sqrt(max(2.0 * float(mean_square), 0.0)) * P.INGEST_SCALE[fmt]
+
+
+#: Precision guard.  The fixed-point channelizers' error is a fraction of the WIDEBAND level whatever the channel holds
+#: (tap rounding x wideband RMS, 1..5 x that on tonal captures, plus a level-independent floor: MfmaPlan.z_error_rms), and
+#: the FM discriminator divides by the channel's own level: audio error ~ 0.024 x error / |z|.  An NFM channel whose
+#: probed level is below guard x (expected z error) is therefore channelized at the next precision that clears it
+#: (measured: a -70 dBFS NFM signal beside a full-scale tone comes out 2.8e-4 RMS off the reference at "fast").
+PRECISION_GUARD = 1000.0
+
+
+def pick_precision(kernel_for, base: str, demod_mode: str | None, channel_power, wideband_rms, guard: float | None = None) -> str:
+    """The cheapest precision, not below ``base``, at which a channel of mean power ``channel_power`` (|z|^2, from the
+    mixer-sign probe) in a capture of wideband RMS ``wideband_rms`` keeps the 1e-4 audio bar.  Only NFM is guarded (AM
+    and SSB do not divide by |z|).  ``kernel_for(precision)`` returns the planned ``_ChannelKernel``."""
+    levels = _ChannelKernel.PRECISIONS
+    guard = PRECISION_GUARD if guard is None else guard
+    if not guard or channel_power is None or wideband_rms is None or (demod_mode or "").lower() not in ("nfm", "fm"):
+        return base
+    level = math.sqrt(max(float(channel_power), 0.0))
+    for name in levels[levels.index(base):]:
+        if name == "float32":
+            break
+        k = kernel_for(name)
+        if k.precision != name:  # (this capture format has no such kernel: uint8 "full", float32 anything)
+            continue
+        err = k.fixed_point_error_rms(wideband_rms)
+        if err <= 0.0 or level >= guard * err:
+            return name
+    return "float32"
+
+
+def base_precision(demod_mode: str | None, agc_enabled: bool) -> str:
+    """SSB with the AGC on is ill-conditioned in the reference itself: ``_apply_agc`` adds 0.001*(target/|s| - gain) per
+    sample for |s| down to 1e-6 (decoders/ssb.py:75-77), so a z difference of 1e-6 near a zero crossing moves the gain
+    by hundreds.  Those targets take the "full" precision (z error below the float32 rounding of z itself); everything
+    else starts at "fast"."""
+    return SSB_AGC_PRECISION if ((demod_mode or "").lower() in ("usb", "lsb", "ssb") and agc_enabled) else "fast"
+
+
+SSB_AGC_PRECISION = "full"
 
 
 class MixSignProbe:
@@ -865,14 +969,19 @@ class MixSignProbe:
     DIRECT_MAX = 65536
 
     def __init__(self, warmup, sample_rate: float, freq_offset: float, taps: np.ndarray, decimation: int, *,
-                 fmt: str = "f32", iq_order: str = "iq", record_done: bool = True, matrix_cores: bool = True):
+                 fmt: str = "f32", iq_order: str = "iq", record_done: bool = True, matrix_cores: bool = True,
+                 measure_level: bool = False):
         """``record_done=False``: the caller sets ``_done`` to event(s) of its own that lie behind both probes (an
         event record between two kernels of a stream costs ~7 us on this part).  ``matrix_cores=False``: the probes go
         through the float32 kernel (a few thousand outputs: tens of microseconds), which -- unlike a ring-kernel launch
-        -- finds room on a CU beside a running channelizer pass."""
+        -- finds room on a CU beside a running channelizer pass.  ``measure_level``: also estimate the wideband level of
+        ``warmup`` (``wideband_rms`` after ``result()`` / ``peek()``: what the precision guard compares ``power`` with)."""
         self._matrix_cores = bool(matrix_cores)
         self._powers = None
         self.power = None
+        self.wideband_rms = None
+        self._fmt = fmt
+        self._level = bool(measure_level)
         self._valid = [False, False]
         x_all, n_in = _as_frames(warmup, fmt)
         if n_in == 0:
@@ -890,18 +999,21 @@ class MixSignProbe:
         if not (self._matrix_cores and self._probe_pair(x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)):
             for i, sign in enumerate((1, -1)):
                 self._probe_one(i, sign, x_all, n_in, x, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order)
+        if self._level:
+            queue_raw_level(warmup, fmt, self._host[2:3])
         self._done = None
         if record_done:
             self._done = D.torch_mod().cuda.Event()
             self._done.record()
 
     @classmethod
-    def from_powers(cls, host_pair, done_event):
+    def from_powers(cls, host_pair, done_event, level_slot=None, fmt: str = "s16"):
         """A probe whose two mean powers (sign +1, sign -1) are being written into ``host_pair`` (a pinned float64[2] the
         caller owns) by launches already queued; ``done_event`` lies behind them.  See ``probe_targets``."""
         self = cls.__new__(cls)
         self._powers, self.power, self._valid, self._sign = host_pair, None, [True, True], None
         self._host, self._done, self._matrix_cores = host_pair, done_event, True
+        self.wideband_rms, self._fmt, self._level, self._level_slot = None, fmt, level_slot is not None, level_slot
         return self
 
     def _probe_pair(self, x_all, n_in, snippet_len, taps, sample_rate, freq_offset, decim, fmt, iq_order) -> bool:
@@ -977,6 +1089,9 @@ class MixSignProbe:
             if power > best_power:
                 best_power, best_sign = power, sign
         self.power = best_power if np.isfinite(best_power) else None  # mean |z|^2 of the chosen sign's probe
+        if self._level:
+            slot = getattr(self, "_level_slot", None)
+            self.wideband_rms = wideband_rms_from(float(slot[0]) if slot is not None else float(host[2]), self._fmt)
         return best_sign
 
     def peek(self) -> int:
@@ -1242,6 +1357,7 @@ class ProcessingPipeline:
         self.keep_channel_audio = False
         self.channelizer_kernel = None  # name of the channelizer kernel that produced the last block of the run
         self.f32_integer_path = True  # float32 captures whose values are all k / 32768 run as int16 on the matrix cores
+        self.channelizer_precision = None  # "fast" / "fine" / "full" / "float32": what the run's channelizer was planned at
 
     def cancel(self) -> None:
         self._cancelled = True
@@ -1301,25 +1417,24 @@ class _Target:
         self.peak = 0.0
         self.output_path = cfg.output_path if cfg.output_path else owner._default_output_path(info)
 
-    def _channelizer(self, sign: int, exact: bool = False, fmt: str | None = None) -> Channelizer:
+    def _channelizer(self, sign: int, exact: bool = False, fmt: str | None = None, precision: str | None = None) -> Channelizer:
         return Channelizer(self.taps, sample_rate=self.sample_rate, freq_offset=self.freq_offset, mix_sign=sign,
-                           decimation=self.decimation, fmt=fmt or self.info.fmt, iq_order=self.cfg.iq_order, exact=exact)
+                           decimation=self.decimation, fmt=fmt or self.info.fmt, iq_order=self.cfg.iq_order, exact=exact,
+                           precision=precision)
 
-    #: Precision guard.  The fixed-point channelizers' error is a fraction of the WIDEBAND level whatever the channel
-    #: holds (~ err_norm x wideband RMS, 1..5 x that on tonal captures), and the FM discriminator divides by the channel's
-    #: own level: audio error ~ 0.024 x error / |z|.  A channel whose probed level is below guard x err_norm x wideband RMS
-    #: is therefore channelized by the float32 kernel (measured: a -70 dBFS NFM signal beside a full-scale tone comes out
-    #: 2.8e-4 RMS off the reference through the default kernel, 1.7e-7 through the float32 one).  0 switches the guard off.
-    precision_guard = 1000.0
+    #: Precision guard (see ``pick_precision``); 0 switches it off.
+    precision_guard = PRECISION_GUARD
 
-    def _guard(self, probe_power, wideband_rms) -> bool:
-        """True when this channel should take the float32 kernel (NFM only: AM and SSB do not divide by |z|)."""
-        if not self.precision_guard or probe_power is None or wideband_rms is None or self.demod is None:
-            return False
-        if (self.cfg.demod_mode or "").lower() not in ("nfm", "fm"):
-            return False
-        norm = self.chan._kernel.fixed_point_error_norm()
-        return norm > 0.0 and math.sqrt(max(probe_power, 0.0)) < self.precision_guard * norm * wideband_rms
+    def _pick_precision(self, probe_power, wideband_rms) -> str:
+        """The precision this target's channelizer runs at: "full" for SSB with the AGC on, otherwise "fast" unless the
+        precision guard asks for more.  A float32 capture that may run as int16 (``f32_integer_path``) is judged by its
+        int16 twin -- that is the kernel its blocks take."""
+        base = "fast" if self.demod is None else base_precision(self.cfg.demod_mode, self.cfg.agc_enabled)
+        fmt = self.info.fmt
+        if fmt == "f32" and getattr(self.owner, "f32_integer_path", False):
+            fmt = "s16"
+        return pick_precision(lambda name: self._channelizer(self.mix_sign, fmt=fmt, precision=name)._kernel, base,
+                              None if self.demod is None else self.cfg.demod_mode, probe_power, wideband_rms, self.precision_guard)
 
     def begin(self, warm) -> None:
         """Launch the mixer-sign probes (asynchronously) and plan the channelizer for the likely sign meanwhile."""
@@ -1330,19 +1445,21 @@ class _Target:
             self.sign_probe = MixSignProbe(warm, self.sample_rate, self.freq_offset, self.taps, self.decimation,
                                            fmt=self.info.fmt, iq_order=self.cfg.iq_order)
             self.chan = self._channelizer(1)
-        self.chan.plan_ahead()
+        self.precision = "fast"
 
     def settle(self, wideband_rms=None) -> None:
+        power = None
         if self.sign_probe is not None:
             self.mix_sign = self.sign_probe.result()
             power = self.sign_probe.power
             self.sign_probe = None
-            if self.mix_sign != 1:
-                self.chan = self._channelizer(self.mix_sign)
-            if self._guard(power, wideband_rms):
-                LOG.info("Channel level %.1f dBFS against a wideband level of %.1f dBFS: float32 channelizer for this target.",
-                         10.0 * math.log10(max(power, 1e-30)), 20.0 * math.log10(max(wideband_rms, 1e-15)))
-                self.chan = self._channelizer(self.mix_sign, exact=True)
+        self.precision = self._pick_precision(power, wideband_rms)
+        if self.precision != "fast" and (self.cfg.demod_mode or "").lower() in ("nfm", "fm"):
+            LOG.info("Channel level %.1f dBFS against a wideband level of %.1f dBFS: '%s' channelizer for this target.",
+                     10.0 * math.log10(max(power or 0.0, 1e-30)), 20.0 * math.log10(max(wideband_rms or 0.0, 1e-15)), self.precision)
+        self.chan = self._channelizer(self.mix_sign, precision=self.precision)
+        self.chan.plan_ahead()
+        self.owner.channelizer_precision = self.precision  # (the decision; a float32 capture's int16 twin runs at it)
         LOG.info("Selected mixer sign %d based on warm-up snippet.", self.mix_sign)
         n_dec_total = -(-self.total // self.decimation)
         self.z_all = D.empty(n_dec_total, "complex64") if (self.pass_through or self.cfg.dump_iq_path) else None
@@ -1534,8 +1651,8 @@ class MultiChannelPipeline:
             # channels that share a decimation share their pass over every block (ChannelBank); built after settle(),
             # which may have replaced a channelizer by the one for the other mixer sign
             banks = []
-            for key in sorted({(t.decimation, t.chan._kernel.exact) for t in targets}):
-                members = [t for t in targets if (t.decimation, t.chan._kernel.exact) == key]  # (float32-guarded channels run alone)
+            for key in sorted({t.decimation for t in targets}):
+                members = [t for t in targets if t.decimation == key]  # (a bank runs its "full" / "float32" members one by one)
                 banks.append((ChannelBank([t.chan for t in members]), members))
             self.banks = [b for b, _ in banks]
             # float32 captures that are integer captures in disguise (every value k / 32768: what SDR software writes for
@@ -1544,7 +1661,7 @@ class MultiChannelPipeline:
             # switches the rest of the run to the float32 kernel (whose state has been carried along all the time).
             banks16 = None
             if info.fmt == "f32" and self.owners[0].f32_integer_path:
-                banks16 = [(ChannelBank([t._channelizer(t.mix_sign, exact=t.chan._kernel.exact, fmt="s16") for t in members]), members)
+                banks16 = [(ChannelBank([t._channelizer(t.mix_sign, precision=t.precision, fmt="s16") for t in members]), members)
                            for _, members in banks]
                 flag16 = D.zeros(1, "int32")
             self.integer_blocks = 0  # blocks of a float32 capture that ran as int16

@@ -359,6 +359,99 @@ def test_mfma_plan_quantisation_is_exact_and_overflow_proof(fs, bw, d):
         assert ps.c_re == 128.0 * float(sl[:64].sum()) and ps.c_im == 128.0 * float(sl[64:].sum())
 
 
+def _emulate_mfma_outputs(mp, raw_s16: np.ndarray, d: int, ms):
+    """What the int16 matrix-core kernels compute for outputs ``ms`` from a plan, in exact integer arithmetic on the
+    host: per group and k-step range 65536*S1 + 256*S2 + 128*sum(T) with S1 = sum q1*hi, S2 = sum q1*lo' + q2*hi (the
+    q2*lo' products are dropped, as the kernels drop them), scaled by the group's unit and added in group order --
+    ``mfma_scaled_sum`` + ``iqa_mfma_combine`` / the chained passes (csrc/mfma_common.h).  No rotation (theta = 0 plans)."""
+    v = raw_s16.astype(np.int64)
+    lo = (v & 255) - 128
+    hi = (v - lo - 128) >> 8
+    assert np.array_equal(256 * hi + lo + 128, v)
+    out = np.zeros(len(ms), dtype=np.complex128)
+    for ps in mp.passes:
+        grp = mp.groups[ps.group]
+        cols = slice(32 * ps.k_first, 32 * (ps.k_first + ps.k_count))
+        t = grp.tq[:, cols].astype(np.int64)
+        q2 = ((t + 128) & 255) - 128
+        q1 = (t - q2) >> 8
+        for i, m in enumerate(ms):
+            s = np.zeros(2, dtype=np.int64)
+            for qq in range(1, 65):  # tap row qq of this group meets data row b = m - (64 q + qq)
+                b = m - (64 * grp.q + qq)
+                first = 2 * (b * d + 1) + cols.start
+                seg = slice(first, first + (cols.stop - cols.start))
+                for comp in (0, 1):
+                    r = comp * 64 + qq - 1
+                    s1 = int((q1[r] * hi[seg]).sum())
+                    s2 = int((q1[r] * lo[seg]).sum() + (q2[r] * hi[seg]).sum())
+                    assert abs(256 * s1 + s2) < 2**31  # what the ring kernel keeps in ONE int32 (per tap row here: a fortiori)
+                    s[comp] += 256 * s1 + s2
+            assert np.all(np.abs(s) < 2**31)
+            c = np.array([ps.c_re, ps.c_im])
+            out[i] += complex(*((256.0 * s + c) * grp.unit))
+    return out
+
+
+@pytest.mark.parametrize("fs,bw,d,max_ks", [(10e6, 12_500.0, 104, None), (2.5e6, 12_500.0, 26, 11), (20e6, 2_800.0, 208, None), (50e6, 12_500.0, 521, 11)])
+def test_mfma_plan_precisions_by_integer_emulation(fs, bw, d, max_ks):
+    """The fixed-point channelizer arithmetic emulated in exact integers on the host against the float64 dot product it
+    stands for, per precision of the plan: "fast" (one group per 64 tap rows, ~14-bit taps under the int32 bound) and
+    "fine" (``residual=True``: high-byte-only taps + their residue as a second group of the same tap rows).  The error
+    must match the plan's own prediction (``z_error_rms``: tap rounding x wideband level + the dropped q2*lo' floor), and
+    the fine plan must be >= 8x closer.  Runs over a full-scale capture (noise + tone), outputs spread over the block."""
+    taps = P.design_channel_filter(fs, bw, d)
+    plan = P.plan_channel(taps, sample_rate=fs, freq_offset=0.0, mix_sign=1, decimation=d, fmt="s16", iq_order="iq")
+    groups_q = max(1, -(-(-(-len(taps) // d)) // P.MFMA_Q))
+    rng = np.random.default_rng(5)
+    n = (64 * groups_q + 40) * d + 64 * d
+    t_ = np.arange(n) / fs
+    x = 0.5 * np.exp(2j * np.pi * 3_000.0 * t_) + 0.25 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    raw = np.rint(np.clip(np.column_stack((x.real, x.imag)), -0.999, 0.999) * 32767.0).astype(np.int16).reshape(-1)
+    wide = float(np.sqrt(np.mean((raw.astype(np.float64) / 32768.0) ** 2) * 2.0))
+    ms = list(range(64 * groups_q + 1, 64 * groups_q + 36, 5))
+    xc = (raw[0::2].astype(np.float64) + 1j * raw[1::2].astype(np.float64))
+    g = plan.taps_natural  # ingest scale folded in
+    want = np.array([np.sum(g[: min(len(g), m * d + 1)] * xc[m * d - np.arange(min(len(g), m * d + 1))]) for m in ms])
+    errs = {}
+    for name, kw in (("fast", dict(acc32=True)), ("fine", dict(acc32=True, residual=True)), ("full", dict(acc32=False, residual=True))):
+        mp = P.plan_mfma(plan, max_ksteps=max_ks, **kw)
+        n_parts = 2 if kw.get("residual") else 1
+        assert [gr.q for gr in mp.groups] == [q for q in range(groups_q) for _ in range(n_parts)]
+        assert [gr.residual for gr in mp.groups] == [part == 1 for _ in range(groups_q) for part in range(n_parts)]
+        if kw.get("residual"):
+            for gr in mp.groups[0::2]:
+                assert not np.any(gr.tq & 255)  # high byte only: nothing for the kernels to drop
+        got = _emulate_mfma_outputs(mp, raw, d, ms) if kw["acc32"] else None
+        if got is None:
+            # 16-bit taps (separate S1/S2 sums: the per-lane kernel): the same arithmetic without the one-int32 bound
+            got = np.zeros(len(ms), dtype=np.complex128)
+            v = raw.astype(np.int64)
+            lo = (v & 255) - 128
+            hi = (v - lo - 128) >> 8
+            for ps in mp.passes:
+                grp = mp.groups[ps.group]
+                c0, c1 = 32 * ps.k_first, 32 * (ps.k_first + ps.k_count)
+                t = grp.tq[:, c0:c1].astype(np.int64)
+                q2 = ((t + 128) & 255) - 128
+                q1 = (t - q2) >> 8
+                for i, m in enumerate(ms):
+                    s = np.zeros(2)
+                    for qq in range(1, 65):
+                        first = 2 * ((m - (64 * grp.q + qq)) * d + 1) + c0
+                        seg = slice(first, first + c1 - c0)
+                        for comp in (0, 1):
+                            r = comp * 64 + qq - 1
+                            s[comp] += 65536.0 * float((q1[r] * hi[seg]).sum()) + 256.0 * float((q1[r] * lo[seg]).sum() + (q2[r] * hi[seg]).sum())
+                    got[i] += complex(*((s + np.array([ps.c_re, ps.c_im])) * grp.unit))
+        err = float(np.sqrt(np.mean(np.abs(got - want) ** 2)))
+        pred = mp.z_error_rms(wide)
+        errs[name] = err
+        assert err < 4.0 * pred + 1e-12, (name, err, pred)  # (7 outputs: a coarse estimate of an RMS)
+    assert errs["fine"] * 8.0 < errs["fast"], errs
+    assert errs["full"] < 3e-8 and errs["full"] <= errs["fine"], errs
+
+
 def test_mfma_interior_with_lead_in_and_slack():
     """dsp_plan.mfma_interior: the outputs whose whole matrix-core read range lies inside the block.  A negative
     `consumed` (a lead-in of zeros in front of frame 0) moves the first interior output down to 0, readable slack
