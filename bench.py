@@ -19,9 +19,14 @@ seed-42 generator, tiled to 60 s in HBM -- SURVEY.md section 8(d)).
 The one JSON line also carries (rank 0, N = 1; all bounded so the default run stays within minutes):
   value_host_resident -- the same step with the 2.4 GB capture starting in PINNED HOST memory every time (H2D inside
                          the timed region, double-buffered): the PCIe-inclusive rate.  Never `value`.
-  configs             -- BASELINE config 1 (the reference's own --benchmark capture, 5 s @ 2.5 MS/s) and config 3
+  configs             -- BASELINE config 1 (the reference's own --benchmark capture, 5 s @ 2.5 MS/s), config 3
                          (60 s @ 20 MS/s, five simultaneous targets nfm/am/usb/lsb/nfm, AGC on; ONE pass of the
-                         channelizer for all targets) with ms_per_step, roofline fraction and parity per target.
+                         channelizer for the "fast" targets, the SSB+AGC targets at "full" precision behind it), config 4's
+                         per-GPU unit (60 s @ 20 MS/s, one channel) and config 5's (1.2 G frames @ 50 MS/s, five NFM
+                         channels, D = 521), each with ms_per_step, dominant kernel, roofline fraction and parity.
+  file_to_wav         -- the LITERAL metric: a PCM16 WAV on disk (tmpfs) -> iq_to_audio_amd ProcessingPipeline.run -> 48 kHz
+                         PCM16 WAV on disk, wall clock around run() as the reference's --benchmark times it
+                         (benchmark.py:104-120), "x realtime" as it prints it, the oracle's DSP time beside it.
   roofline.traffic    -- HBM bytes per launch from separate rocprofv3 --pmc passes of this command (profiles/), tagged
                          with its source; null when no matching profile is committed.  It is NOT measured in this run.
 
@@ -29,6 +34,11 @@ N > 1 (launched by torch.distributed.run): every rank processes its own independ
 (BASELINE config 4 pattern, seeds 42+rank), no data-path collective, only the finished 48 kHz
 PCM16 audio is gathered to rank 0 over RCCL (iq_to_audio_amd.dist.AudioGather: asynchronously, overlapping
 the next step).  scaling = "weak".
+
+--axis channels (any N): BASELINE config 5 -- ONE 120 s @ 50 MS/s capture (24 GB) on rank 0, replicated with one RCCL
+broadcast (timed apart: config.broadcast_s), its 40 NFM channels in contiguous shares of ceil(40/N) per rank, every
+rank's share extracted as one bank per step (iq_to_audio_amd.dist.ShardedJob + batch.ResidentBankRunner), every
+channel's 48 kHz PCM16 gathered on rank 0 per step.  Total work is fixed: scaling = "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -74,7 +84,11 @@ def parse_args():
     ap.add_argument("--unique-seconds", type=float, default=5.0, help="seed-42 prefix generated on the host, then tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
-    ap.add_argument("--no-extras", action="store_true", help="skip value_host_resident and the configs array")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_host_resident, the configs array and file_to_wav")
+    ap.add_argument("--axis", choices=("captures", "channels"), default="captures",
+                    help="captures (default): one independent capture per GPU (BASELINE configs 2 / 4); channels: BASELINE "
+                         "config 5 -- one 50 MS/s capture broadcast to every GPU, its 40 channels sharded")
+    ap.add_argument("--channels", type=int, default=40, help="--axis channels: NFM channels of the capture (config 5: 40)")
     return ap.parse_args()
 
 
@@ -102,19 +116,22 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     import iq_to_audio_amd as A
     from iq_to_audio_amd import dsp_plan as P
     from iq_to_audio_amd.batch import ResidentCaptureRunner
+    from iq_to_audio_amd.benchmark import synthetic_iq_s16
     from oracle import cpu_ref as O
 
     fs, secs, f_off = 2.5e6, 5.0, 25e3
     n = int(round(fs * secs))
     d, fs_ch = P.choose_decimation(fs, 96_000.0)
     taps = A.design_channel_filter(fs, 12_500.0, d)
-    host = O.synth_capture_s16(fs, secs, f_off).reshape(-1)
+    host = synthetic_iq_s16(fs, secs, f_off).reshape(-1)  # (the product's generator = the reference's, benchmark.py:19-38)
     _, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
     buf = padded_resident(host, n, slack)
     raw = buf[: 2 * n]
     torch.cuda.synchronize()
+    # eight captures in flight: with two, every 85 us step is a host round trip (event wait + wake-up + graph launch),
+    # which the round-2 driver box took 0.236 ms for where the builder's boxes took 0.085
     runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch,
-                                   chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n)
+                                   chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n, slots=8)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     ts = [runner.submit(raw, enclosing=buf, lead_frames=0, resident=True) for _ in range(warm)]
     for t in ts:
@@ -131,23 +148,27 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
         runner.collect(t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ts = [runner.submit_captured(raw, enclosing=buf, lead_frames=0) for _ in range(steps)]
+    ts, host_us = [], []
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        ts.append(runner.submit_captured(raw, enclosing=buf, lead_frames=0))  # (waits for the capture `slots` back first)
+        host_us.append((time.perf_counter() - h0) * 1e6)
     res = [runner.collect(t) for t in ts][-1]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     # ... and two captures per graph (a batch of captures in fixed buffers: one graph launch for both)
-    pair = [(raw, buf, 0)] * runner.SLOTS
-    for _ in range(warm // runner.SLOTS):
+    pair = [(raw, buf, 0)] * 2
+    for _ in range(warm // 2):
         for t in runner.submit_captured_batch(pair):
             runner.collect(t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    batches = -(-steps // runner.SLOTS)
+    batches = -(-steps // 2)
     for _ in range(batches):
         for t in runner.submit_captured_batch(pair):
             res_b = runner.collect(t)
     torch.cuda.synchronize()
-    dt_batch = (time.perf_counter() - t0) / (batches * runner.SLOTS)
+    dt_batch = (time.perf_counter() - t0) / (batches * 2)
     want = O.run_chain(host, sample_rate=fs, freq_offset=f_off, keep_decimated=False)
     audio = res["audio"].cpu().numpy()
     audio_b = res_b["audio"].cpu().numpy()
@@ -156,8 +177,11 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
         "workload": "BASELINE config 1 (the reference's --benchmark capture): 5 s @ 2.5 MS/s int16 I/Q, 1 NFM channel, +25 kHz, "
                     f"bw 12.5 kHz, D={d}, {len(taps)} taps",
         "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
-        "step": "captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured)",
-        "ms_per_step_direct_launches": round(dt_eager * 1e3, 4), "replays_redone_for_sign": int(getattr(runner, "replays_redone", 0)),
+        "step": f"captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured), {runner.SLOTS} captures in flight",
+        "host_us_per_replay": {"mean": round(float(np.mean(host_us)), 1), "median": round(float(np.median(host_us)), 1),
+                               "max": round(float(np.max(host_us)), 1),
+                               "note": "host time inside submit_captured: wait for the capture `slots` back + hipGraphLaunch + event record"},
+        "ms_per_step_direct_launches": round(dt_eager * 1e3, 4), "replays_redone": dict(runner.redone),
         "ms_per_step_two_captures_per_graph": round(dt_batch * 1e3, 4), "two_per_graph_audio_identical": bool(np.array_equal(audio, audio_b)),
         "roofline": {"kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                      "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -167,9 +191,28 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     }
 
 
+def _bank_traffic_ratio(tag_key: str):
+    """(ratio, source) of measured HBM traffic over algorithmic bytes for a bank workload, from the committed rocprofv3 PMC
+    summary (profiles/pmc_bank.sh); (None, reason) when no matching profile is committed."""
+    for name in ("r03_bank_pmc_summary.json", "r02c_bank_pmc_summary.json"):
+        path = ROOT / "profiles" / name
+        if not path.exists():
+            continue
+        try:
+            rec = json.loads(path.read_text())
+        except ValueError:
+            continue
+        ratio = rec.get("channelizer_stage_traffic_over_algorithmic")
+        if ratio is not None and rec.get("workload_key", "c3_all_fast") == tag_key:
+            return float(ratio), f"profiles/{name} (separate rocprofv3 --pmc passes of profiles/bench_bank.py; NOT measured in this run)"
+    return None, f"no committed PMC profile for workload {tag_key!r}"
+
+
 def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 0.55) -> dict:
     """BASELINE config 3: 60 s @ 20 MS/s, five simultaneous targets (nfm/am/usb/lsb/nfm, bw 12.5k/10k/2.8k/2.8k/12.5k),
-    AGC on -- one pass of the channelizer over the capture for all targets (ResidentBankRunner)."""
+    AGC on (ResidentBankRunner).  Timed twice: at the precisions the product chooses (USB / LSB with the AGC on at "full":
+    chained passes of the per-lane kernel behind the shared pass of the three "fast" targets -- what keeps their audio at
+    the 1e-4 bar) and with every target forced to "fast" (round 2's launch: ONE pass for all)."""
     import torch
 
     from iq_to_audio_amd import dsp_plan as P
@@ -186,7 +229,149 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
     buf = padded_resident(host, n, slack)
     raw = buf[: 2 * n]
     torch.cuda.synchronize()
-    runner = ResidentBankRunner(C3_TARGETS, sample_rate=fs, n_frames=n)
+
+    def timed(targets):
+        runner = ResidentBankRunner(targets, sample_rate=fs, n_frames=n)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for t in [runner.submit(raw, enclosing=buf, lead_frames=0) for _ in range(warm)]:
+            runner.collect(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ts = [runner.submit(raw, events=ev[i], enclosing=buf, lead_frames=0) for i in range(steps)]
+        res = [runner.collect(t) for t in ts][-1]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])), ts[-1], res, runner
+
+    dt_fast, chan_fast, tk_fast, _, r_fast = timed([dict(t, precision="fast") for t in C3_TARGETS])
+    del r_fast
+    torch.cuda.empty_cache()
+    dt, chan_ms, tk, res, runner = timed(C3_TARGETS)
+    launch = tk["launch"]
+    # parity per target on the un-tiled prefix (whole reference chunks are not needed: the oracle sees the same frames)
+    n_cpu = int(round(cpu_seconds_of_signal * fs))
+    parity = []
+    for spec, r in zip(C3_TARGETS, res):
+        want = O.run_chain(host[: 2 * n_cpu], sample_rate=fs, freq_offset=spec["freq_offset"], bandwidth=spec["bandwidth"],
+                           demod_mode=spec["demod_mode"], agc_enabled=True)
+        k = want.audio.size - 64  # (the capture continues behind the oracle's sample: its last outputs see other frames)
+        z_err = rms_err(np.abs(r["z"][:k].cpu().numpy() - want.decimated[:k]), 0.0)
+        entry = {"target": f'{spec["demod_mode"]} {spec["freq_offset"]:+.0f} Hz bw {spec["bandwidth"]:.0f}', "sign": r["sign"],
+                 "precision": r["precision"], "z_rms_err": z_err, "samples_compared": int(k),
+                 "audio_rms_err": rms_err(r["audio"][:k].cpu().numpy(), want.audio[:k])}
+        if spec["demod_mode"] in ("usb", "lsb"):
+            entry["note"] = ("SSB + AGC is ill-conditioned in the reference (DESIGN.md section 5: its own output moves by ~2e-3 RMS for a "
+                             "3e-7 change of z); held link by link in tests/test_gpu_configs.py")
+        parity.append(entry)
+    algo = 4.0 * n + len(C3_TARGETS) * 4.0 * 48_000.0 / fs * n
+    # Algorithmic matrix work: the decimating FIR needs 4 L / D real 16 x 16-bit MACs per input frame and channel; on int8
+    # pieces one such MAC is three int8 MACs (q1 hi, q1 lo, q2 hi) = 6 int8 ops.  (The launches execute more: tap rows are
+    # allocated in groups of 64 per component, and a "full"-precision target runs every group twice: taps + their residue.)
+    taps = [len(P.design_channel_filter(fs, t["bandwidth"], d)) for t in C3_TARGETS]
+    int8_ops = 6.0 * 4.0 * sum(taps) / d * n
+    ratio, ratio_src = _bank_traffic_ratio("c3_product_precisions")
+    ratio_fast, ratio_fast_src = _bank_traffic_ratio("c3_all_fast")
+    return {
+        "workload": "BASELINE config 3: 60 s @ 20 MS/s int16 I/Q, 5 simultaneous targets nfm/am/usb/lsb/nfm "
+                    f"({'/'.join(str(t) for t in taps)} taps), AGC on, D={d}; precisions {'/'.join(r['precision'] for r in res)}",
+        "value": round(n / dt / 1e6, 1), "unit": "MS/s of capture", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        "channel_samples_per_s": round(len(C3_TARGETS) * n / dt / 1e9, 2),
+        "replays_redone": dict(runner.redone),
+        "roofline": {"bound": "mfma", "kernel": "k_channelize_mfma_s16_ring" + ("_pairs" if launch and launch.get("pairs") else "_multi")
+                                               + " (shared pass) + k_channelize_mfma_s16 (the 'full'-precision targets' chained passes)",
+                     "launch": launch, "kernel_ms": round(chan_ms, 4),
+                     "note": "kernel_ms = every channelizer launch of a capture on the caller's stream, by events: the shared multi-lane "
+                             "pass of the 'fast' targets and the chained per-lane passes of the 'full' ones (the combine launches run on "
+                             "the side stream and are not in it); achieved = algorithmic int8 ops (3 int8 MACs per 16x16-bit tap x sample "
+                             "MAC) / kernel time; peak = dense int8 MFMA (2 x the 2.5 PFLOP/s bf16 figure of MI355X_MICROARCH.md)",
+                     "achieved": round(int8_ops / (chan_ms * 1e-3) / 1e12, 1), "peak": 5000.0, "unit": "TOP/s",
+                     "frac": round(int8_ops / (chan_ms * 1e-3) / 1e12 / 5000.0, 5), "algorithmic_int8_ops_per_launch": int8_ops,
+                     "hbm": {"algorithmic_bytes_per_launch": algo, "achieved_gb_per_s": round(algo / (chan_ms * 1e-3) / 1e9, 2),
+                             "frac_of_8_tb_per_s": round(algo / (chan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                             "traffic_over_algorithmic": ratio, "traffic_source": ratio_src}},
+        "all_targets_fast": {"note": "the same capture with every target forced to precision 'fast' (round 2's launch: ONE multi-lane pass for "
+                                     "all five targets; SSB+AGC audio then 2e-2 .. 8e-2 RMS off the reference)",
+                             "ms_per_step": round(dt_fast * 1e3, 3), "kernel_ms": round(chan_fast, 4), "launch": tk_fast["launch"],
+                             "mfma_frac": round(int8_ops / (chan_fast * 1e-3) / 1e12 / 5000.0, 5),
+                             "traffic_over_algorithmic": ratio_fast, "traffic_source": ratio_fast_src},
+        "parity": {"bar": 1e-4, "per_target": parity},
+    }
+
+
+def sub_bench_c4_unit(steps: int = 60, warm: int = 60, cpu_seconds_of_signal: float = 0.5) -> dict:
+    """BASELINE config 4's per-GPU unit: 60 s @ 20 MS/s int16, one NFM channel (D = 208, 12 801 taps, 13 k steps: the
+    ring kernel without loader waves), through the same runner as the headline."""
+    import torch
+
+    import iq_to_audio_amd as A
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentCaptureRunner
+    from iq_to_audio_amd.benchmark import synthetic_iq_s16
+    from oracle import cpu_ref as O
+
+    fs, secs, f_off, uniq = 20e6, 60.0, 25e3, 2.0
+    n = int(round(fs * secs))
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    host = synthetic_iq_s16(fs, uniq, f_off).reshape(-1)
+    _, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    buf = padded_resident(host, n, slack)
+    raw = buf[: 2 * n]
+    torch.cuda.synchronize()
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch,
+                                   chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for t in [runner.submit(raw, enclosing=buf, lead_frames=0, resident=True) for _ in range(warm)]:
+        runner.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = [runner.submit(raw, events=ev[i], enclosing=buf, lead_frames=0, resident=True) for i in range(steps)]
+    res = [runner.collect(t) for t in ts][-1]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    n_cpu = int(round(cpu_seconds_of_signal * fs))
+    want = O.run_chain(host[: 2 * n_cpu], sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+    k = want.audio.size - 64
+    algo = (4.0 + 4.0 * 48_000.0 / fs) * n
+    return {
+        "workload": f"BASELINE config 4, one GPU's unit: 60 s @ 20 MS/s int16 I/Q, 1 NFM channel, +25 kHz, bw 12.5 kHz, D={d}, {len(taps)} taps",
+        "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warm,
+        "roofline": {"bound": "hbm", "kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
+                     "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+        "parity": {"rms_err_vs_oracle_fs_channel": rms_err(res["audio"][:k].cpu().numpy(), want.audio[:k]), "samples_compared": int(k),
+                   "precision": res["precision"], "sign": res["sign"], "bar": 1e-4},
+    }
+
+
+def c5_targets(n_channels: int = 40) -> list:
+    """BASELINE config 5: NFM carriers on a 100 kHz raster from -1.95 MHz, amplitude 0.02 each."""
+    return [dict(freq_offset=-1.95e6 + 100e3 * k, demod_mode="nfm", bandwidth=12_500.0) for k in range(n_channels)]
+
+
+def sub_bench_c5_unit(steps: int = 20, warm: int = 6, uniq: float = 0.2) -> dict:
+    """BASELINE config 5's per-GPU unit: five of the 40 NFM channels (first, second, the two around DC, last) of a
+    50 MS/s capture, D = 521 (row-staged ring slots, 33 k steps in three chained launches of five lanes), on 1.2 G frames
+    (24 s of the 120 s capture: the same per-frame work, a fifth of its length)."""
+    import torch
+
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentBankRunner, ResidentCaptureRunner
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+    from oracle import cpu_ref as O
+
+    fs, n = 50e6, 1_200_000_000
+    d, _ = P.choose_decimation(fs, 96_000.0)
+    every = c5_targets(40)
+    picks = [0, 1, 19, 20, 39]
+    targets = [every[k] for k in picks]
+    host = synthetic_multi_iq_s16(fs, uniq, [(t["freq_offset"], 0.02, "nfm") for t in every]).reshape(-1)
+    slack = max(ResidentCaptureRunner.padded_capture_frames(d, 32_001)[1], 8192)
+    buf = padded_resident(host, n, slack)
+    raw = buf[: 2 * n]
+    torch.cuda.synchronize()
+    runner = ResidentBankRunner(targets, sample_rate=fs, n_frames=n)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     for t in [runner.submit(raw, enclosing=buf, lead_frames=0) for _ in range(warm)]:
         runner.collect(t)
@@ -198,47 +383,76 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
     dt = (time.perf_counter() - t0) / steps
     chan_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     launch = ts[-1]["launch"]
-    # parity per target on the un-tiled prefix (whole reference chunks are not needed: the oracle sees the same frames)
-    n_cpu = int(round(cpu_seconds_of_signal * fs))
     parity = []
-    for spec, r in zip(C3_TARGETS, res):
-        want = O.run_chain(host[: 2 * n_cpu], sample_rate=fs, freq_offset=spec["freq_offset"], bandwidth=spec["bandwidth"],
-                           demod_mode=spec["demod_mode"], agc_enabled=True)
-        k = want.audio.size - 64  # (the capture continues behind the oracle's sample: its last outputs see other frames)
-        z_err = rms_err(np.abs(r["z"][:k].cpu().numpy() - want.decimated[:k]), 0.0)
-        entry = {"target": f'{spec["demod_mode"]} {spec["freq_offset"]:+.0f} Hz bw {spec["bandwidth"]:.0f}', "sign": r["sign"],
-                 "z_rms_err": z_err, "samples_compared": int(k)}
-        if spec["demod_mode"] in ("usb", "lsb"):
-            entry["note"] = ("SSB + AGC is ill-conditioned in the reference (DESIGN.md section 5): the audio is held link by "
-                             "link in tests/test_gpu_configs.py; z is the parity figure here")
-        else:
-            entry["audio_rms_err"] = rms_err(r["audio"][:k].cpu().numpy(), want.audio[:k])
-        parity.append(entry)
-    algo = 4.0 * n + len(C3_TARGETS) * 4.0 * 48_000.0 / fs * n
-    # With the ingest shared the launch is bound by the int8 matrix pipe, not by HBM.  Algorithmic matrix work: the
-    # decimating FIR needs 4 L / D real 16 x 16-bit MACs per input frame and channel; on int8 pieces one such MAC is
-    # three int8 MACs (q1 hi, q1 lo, q2 hi) = 6 int8 ops.  (The launch executes more: tap rows are allocated in groups
-    # of 64 per component -- 640 rows for the 517 these five filters have.)
-    taps = [len(P.design_channel_filter(fs, t["bandwidth"], d)) for t in C3_TARGETS]
-    int8_ops = 6.0 * 4.0 * sum(taps) / d * n
+    for spec, r in list(zip(targets, res))[:: len(targets) - 1]:  # first and last channel (the oracle takes ~3 s per channel)
+        want = O.run_chain(host, sample_rate=fs, freq_offset=spec["freq_offset"], bandwidth=spec["bandwidth"], demod_mode="nfm")
+        k = want.audio.size - 64
+        parity.append({"target": f'nfm {spec["freq_offset"]:+.0f} Hz', "sign": r["sign"], "precision": r["precision"], "samples_compared": int(k),
+                       "z_rms_err": rms_err(np.abs(r["z"][:k].cpu().numpy() - want.decimated[:k]), 0.0),
+                       "audio_rms_err": rms_err(r["audio"][:k].cpu().numpy(), want.audio[:k])})
+    algo = 4.0 * n + len(targets) * 4.0 * 48_000.0 / fs * n
+    ntaps = len(P.design_channel_filter(fs, 12_500.0, d))
+    int8_ops = 6.0 * 4.0 * len(targets) * ntaps / d * n
     return {
-        "workload": "BASELINE config 3: 60 s @ 20 MS/s int16 I/Q, 5 simultaneous targets nfm/am/usb/lsb/nfm "
-                    f"({'/'.join(str(t) for t in taps)} taps = {launch['lanes'] if launch else '?'} tap-row-group lanes), AGC on, D={d}",
+        "workload": f"BASELINE config 5, one GPU's unit: 1.2 G frames (24 s) @ 50 MS/s int16 I/Q, {len(targets)} of the 40 NFM channels, "
+                    f"D={d}, {ntaps} taps, 33 k steps in three chained launches",
         "value": round(n / dt / 1e6, 1), "unit": "MS/s of capture", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-        "channel_samples_per_s": round(len(C3_TARGETS) * n / dt / 1e9, 2),
-        "roofline": {"bound": "mfma", "kernel": ts[-1]["kernel"] + ("_pairs" if launch and launch.get("pairs") else "_multi"), "launch": launch,
-                     "kernel_ms": round(chan_ms, 4),
-                     "note": "kernel_ms = the one multi-lane channelizer pass (+ its combine launches) per capture, by events; "
-                             "achieved = algorithmic int8 ops (3 int8 MACs per 16x16-bit tap x sample MAC) / kernel time; peak = dense "
-                             "int8 MFMA (2 x the 2.5 PFLOP/s bf16 figure of MI355X_MICROARCH.md)",
+        "channel_samples_per_s": round(len(targets) * n / dt / 1e9, 2), "replays_redone": dict(runner.redone),
+        "roofline": {"bound": "mfma", "kernel": "k_channelize_mfma_s16_ring_rows_multi", "launch": launch, "kernel_ms": round(chan_ms, 4),
                      "achieved": round(int8_ops / (chan_ms * 1e-3) / 1e12, 1), "peak": 5000.0, "unit": "TOP/s",
                      "frac": round(int8_ops / (chan_ms * 1e-3) / 1e12 / 5000.0, 5), "algorithmic_int8_ops_per_launch": int8_ops,
                      "hbm": {"algorithmic_bytes_per_launch": algo, "achieved_gb_per_s": round(algo / (chan_ms * 1e-3) / 1e9, 2),
-                             "frac_of_8_tb_per_s": round(algo / (chan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                             "traffic_over_algorithmic": 1.17, "traffic_source": "profiles/r02c_bank_pmc_summary.json (separate rocprofv3 "
-                                                                                 "--pmc passes of profiles/bench_bank.py; NOT measured in this run)"}},
+                             "frac_of_8_tb_per_s": round(algo / (chan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}},
         "parity": {"bar": 1e-4, "per_target": parity},
     }
+
+
+def file_to_wav_legs() -> list:
+    """The literal metric -- file in, 48 kHz WAV out -- as the reference's --benchmark times it (benchmark.py:104-120): a
+    PCM16 stereo WAV on disk -> ProcessingPipeline.run -> 48 kHz PCM16 WAV on disk, wall clock around run(), generation of
+    the capture outside.  In a tmpfs (/dev/shm) so that the figure is the pipeline's, not a disk's.  Beside it the oracle's
+    DSP time on the same frames (in memory: the reference's own run() needs ffmpeg, which no box here has)."""
+    import shutil
+
+    from iq_to_audio_amd.benchmark import synthetic_iq_s16, timed_file_run
+    from oracle import cpu_ref as O
+
+    tmp_root = "/dev/shm" if (os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)) else None
+    legs = []
+    for label, fs, secs, repeats in (("BASELINE config 1 (the reference's --benchmark): 5 s @ 2.5 MS/s", 2.5e6, 5.0, 3),
+                                     ("config 2's rate: 10 s @ 10 MS/s", 10e6, 10.0, 2)):
+        f_off, fc = 25e3, 400e6
+        try:
+            free = shutil.disk_usage(tmp_root or "/tmp").free
+            if free < 3 * 4 * fs * secs:
+                raise RuntimeError(f"not enough room in {tmp_root or '/tmp'} ({free} bytes free)")
+            run = timed_file_run(seconds=secs, sample_rate=fs, tone_offset=f_off, center_freq=fc, target_freq=fc + f_off,
+                                 settings=dict(bandwidth=12_500.0, chunk_size=1_048_576), mode="nfm", tmp_root=tmp_root, repeats=repeats,
+                                 keep_audio=True)
+            raw = synthetic_iq_s16(fs, secs, f_off)
+            t1 = time.perf_counter()
+            want = O.run_chain(raw, sample_rate=fs, freq_offset=f_off, keep_decimated=False)
+            ref48 = O.float_to_pcm16(O.resample_48k(want.audio, want.fs_channel))
+            cpu_s = time.perf_counter() - t1
+            pcm = run["audio_48k"]
+            same = pcm.size == ref48.size
+            legs.append({
+                "workload": f"{label}, int16 stereo WAV in {'tmpfs' if tmp_root else '/tmp'} -> ProcessingPipeline.run -> 48 kHz PCM16 WAV",
+                "frames": run["frames"], "wall_s_first_run": round(run["runs_s"][0], 4), "wall_s_later_runs": [round(t, 4) for t in run["runs_s"][1:]],
+                "value": round(run["frames"] / min(run["runs_s"]) / 1e6, 1), "unit": "MS/s (best run)",
+                "value_first_run": round(run["frames"] / run["runs_s"][0] / 1e6, 1),
+                "x_realtime_first_run": round(secs / run["runs_s"][0], 1), "x_realtime_best": round(secs / min(run["runs_s"]), 1),
+                "note": "wall clock around run(): header parse, memory-mapped read, pinned staging, H2D, probes, channelizer, demodulator, "
+                        "48 kHz resampler, PCM16, D2H, WAV write; the first run also pays plan creation, tap uploads and pinning",
+                "oracle": {"dsp_wall_s": round(cpu_s, 3), "value": round(run["frames"] / cpu_s / 1e6, 2), "unit": "MS/s", "cores": 1,
+                           "x_realtime": round(secs / cpu_s, 2),
+                           "note": "oracle/cpu_ref.run_chain + resample_48k on the same frames in memory (no file I/O, no ffmpeg processes)"},
+                "parity": {"sample_count_exact": bool(same), "mix_sign": int(run["result"].mix_sign),
+                           "pcm16_max_abs_diff_lsb": int(np.max(np.abs(pcm.astype(np.int32) - ref48.astype(np.int32)))) if same else None},
+            })
+        except Exception as exc:  # noqa: BLE001 - an extra must never take the headline down
+            legs.append({"workload": label, "error": repr(exc)})
+    return legs
 
 
 def host_resident_leg(runner, host_pinned, bufs, n_total: int, captures: int = 8) -> dict:
@@ -257,18 +471,119 @@ def host_resident_leg(runner, host_pinned, bufs, n_total: int, captures: int = 8
         torch.cuda.current_stream().wait_event(ev)
         return runner.submit(buf[: 2 * n_total], enclosing=buf, lead_frames=0)
 
-    for t in [step(i) for i in range(2)]:
-        runner.collect(t)
+    def run(count):
+        # capture i reuses the buffer of capture i - 2: that one is collected (its kernels have read the buffer) before the
+        # upload of capture i is queued
+        tickets = []
+        for i in range(count):
+            if i >= 2:
+                runner.collect(tickets[i - 2])
+            tickets.append(step(i))
+        for t in tickets[-2:]:
+            runner.collect(t)
+
+    run(2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in [step(i) for i in range(captures)]:
-        runner.collect(t)
+    run(captures)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / captures
     return {"value": round(n_total / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 2), "steps": captures,
             "pcie_gb_per_s": round(4.0 * n_total / dt / 1e9, 1),
             "note": "capture in pinned host memory at the start of every step (H2D inside the timed region, double-buffered); "
                     "bounded by the PCIe link, not the GPU"}
+
+
+def main_channel_axis(args, json_fd: int) -> None:
+    """``--axis channels``: BASELINE config 5 -- one 120 s @ 50 MS/s capture, its 40 NFM channels sharded over the ranks
+    (5 per GPU at N = 8).  What a rank executes is ``dist.ShardedJob`` (one broadcast, then steps of stage + gather: the
+    functions tests/test_dist_gloo.py drives at world 2 and 3) around ``batch.ResidentBankRunner`` (one shared-ingest pass
+    per step for the rank's channels).  ref: the reference's sequential loop over --ft targets, each re-reading the file
+    (cli.py:683-710)."""
+    import torch
+
+    import iq_to_audio_amd as A
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dist as DS
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentBankRunner, ResidentCaptureRunner
+    from iq_to_audio_amd.benchmark import synthetic_multi_iq_s16
+
+    rank, world, local_rank = DS.check_launch_env(args.gpus, torch.cuda.device_count())
+    A.native.lib()
+    distributed = world > 1 or bool(os.environ.get("IQA_FORCE_DIST") or os.environ.get("IQA_BENCH_FORCE_DIST"))
+    if distributed:
+        os.environ.setdefault("IQA_FORCE_DIST", "1")
+    torch.cuda.set_device(local_rank)
+    A.native.require_gpu()
+    if distributed:
+        DS.init_from_env("nccl", high_priority=True)
+    fs = 50e6 if args.sample_rate == 10e6 else float(args.sample_rate)  # (the default --sample-rate is config 2's)
+    secs = 120.0 if args.seconds == 60.0 else float(args.seconds)
+    n_total = int(round(fs * secs))
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    targets = c5_targets(args.channels)
+    slack = max(ResidentCaptureRunner.padded_capture_frames(d, 32_001)[1], 8192)
+    numel = 2 * (n_total + slack)
+    buf0 = None
+    if rank == 0:
+        uniq = min(secs, 0.2)
+        host = synthetic_multi_iq_s16(fs, uniq, [(t["freq_offset"], 0.02, "nfm") for t in targets]).reshape(-1)
+        buf0 = padded_resident(host, n_total, slack)
+        torch.cuda.synchronize()
+    job = DS.ShardedJob(targets, shared=dict(tensor=buf0, numel=numel, dtype=torch.int16, device=D.device()), sync=torch.cuda.synchronize)
+    buf = job.common
+    raw = buf[: 2 * n_total]
+    mine = job.my_units()
+    runner = ResidentBankRunner(mine, sample_rate=fs, n_frames=n_total) if mine else None
+
+    def stage(units, capture):
+        res = runner.collect(runner.submit(raw, enclosing=buf, lead_frames=0))
+        return [(torch.from_numpy(r["pcm_host"].numpy().copy()).to(D.device()), r["demod"].peak) for r in res]
+
+    steps = args.steps if args.steps != 1000 else 5  # (the defaults of the capture axis are sized for 0.7 ms steps)
+    warm = args.warmup if args.warmup != 100 else 2
+    for _ in range(warm):
+        job.step(stage)
+    DS.fence(None, sync=torch.cuda.synchronize)
+    t0 = time.perf_counter()
+    got = peak = None
+    for _ in range(steps):
+        got, peak = job.step(stage)
+    DS.fence(None, sync=torch.cuda.synchronize)
+    elapsed = DS.max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = elapsed / steps * 1e3
+    algo = 4.0 * n_total + len(targets) * 4.0 * 48_000.0 / fs * n_total
+    out = {
+        "metric": "complex IQ MS/s end-to-end (ingest->48 kHz audio)", "value": round(n_total / (elapsed / steps) / 1e6, 1), "unit": "MS/s",
+        "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE config 5: ONE synthetic {secs:g} s @ {fs/1e6:g} MS/s int16 I/Q capture ({numel * 2 / 1e9:.1f} GB), "
+                        f"{len(targets)} NFM channels (100 kHz raster, bw 12.5 kHz, de-emphasis), D={d}",
+            "axis": "channels", "frames": n_total, "channels": len(targets), "channels_per_gpu": -(-len(targets) // world),
+            "parallelism": f"the capture on every GPU (one RCCL broadcast from rank 0, {job.broadcast_s:.3f} s, outside the timed steps); "
+                           f"{-(-len(targets) // world)} channels per GPU extracted in one pass per step; RCCL gather of 48 kHz PCM16 only",
+            "broadcast_s": round(job.broadcast_s, 4),
+            "broadcast_gb_per_s": round(numel * 2 / job.broadcast_s / 1e9, 1) if (world > 1 and job.broadcast_s > 0) else None,
+            "channel_samples_per_s_G": round(len(targets) * n_total / (elapsed / steps) / 1e9, 2),
+            "audio_units_gathered": len(got) if got is not None else None, "audio_peak": peak,
+            "value_is": "frames of the capture per second with ALL channels extracted (total work fixed as N grows)",
+        },
+        "roofline": {"bound": "hbm", "kernel": "k_channelize_mfma_s16_ring_rows_multi", "achieved": round(algo / (elapsed / steps) / 1e9, 2),
+                     "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": round(algo / (elapsed / steps) / 1e9 / (HBM_PEAK_GBPS * world), 5),
+                     "traffic": None, "note": "whole step (all launches, demodulators, resamplers, gather) against N x 8 TB/s on the algorithmic "
+                                              "bytes 4 B/frame + 4 B x 48 kHz per channel; the per-kernel figure of this shape is configs[3] of the default run"},
+    }
+    if distributed:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main() -> None:
@@ -279,6 +594,8 @@ def main() -> None:
     json_fd = os.dup(1)
     os.dup2(2, 1)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (see iq_to_audio_amd/__init__.py; before the runtime initialises)
+    if args.axis == "channels":
+        return main_channel_axis(args, json_fd)
     import torch
 
     import iq_to_audio_amd as A
@@ -479,6 +796,9 @@ def main() -> None:
             "sample": f"first {n_cpu} frames ({n_cpu / fs:.2f} s of signal) of the same capture, oracle/cpu_ref.run_chain "
                       f"(fp64 NCO + complex128 131072-pt scipy.fft overlap-save + slice decimate + NFM), "
                       f"{cpu_s:.1f} s on 1 of {os.cpu_count()} host cpus (1-D FFTs are single-threaded)",
+            "note": "the REFERENCE's own stage classes, timed in the survey container (8 vCPU Xeon 2.1 GHz, DSP stages only, no ffmpeg; "
+                    "SURVEY.md section 6): 9.4 MS/s at config 1's parameters, 4.2 MS/s at 10 MS/s parameters (this config), 3.4 MS/s at "
+                    "50 MS/s parameters -- the reference cannot run on the GPU box (it does not travel)",
         }
         out["parity"] = {"rms_err_vs_oracle_fs_channel": rms_err(got, ref.audio), "samples_compared": int(ref.audio.size), "bar": 1e-4}
 
@@ -495,13 +815,17 @@ def main() -> None:
         torch.cuda.empty_cache()
         # -- the other single-GPU BASELINE configurations ------------------------------------------------------
         out["configs"] = []
-        for fn in (sub_bench_c1, sub_bench_c3):
+        for fn in (sub_bench_c1, sub_bench_c3, sub_bench_c4_unit, sub_bench_c5_unit):
             try:
                 out["configs"].append(fn())
             except Exception as exc:  # noqa: BLE001
                 out["configs"].append({"workload": fn.__name__, "error": repr(exc)})
             gc.collect()
             torch.cuda.empty_cache()
+        # -- the literal metric: file in, 48 kHz WAV out, as the reference's --benchmark times it ----------------------
+        out["file_to_wav"] = file_to_wav_legs()
+        gc.collect()
+        torch.cuda.empty_cache()
 
     if distributed:
         import torch.distributed as dist

@@ -54,10 +54,18 @@ class ResidentCaptureRunner:
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
                  fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, precision: str | None = None,
-                 precision_guard: float | None = None):
+                 precision_guard: float | None = None, slots: int | None = None):
         """``precision``: the channelizer precision every capture starts at (default: by demodulator,
-        ``processing.base_precision``); ``precision_guard``: see ``processing.PRECISION_GUARD`` (0 = off)."""
+        ``processing.base_precision``); ``precision_guard``: see ``processing.PRECISION_GUARD`` (0 = off).
+        ``slots``: captures in flight (output buffers; default 2).  ``submit`` of capture i first waits for capture
+        i - slots: with captures of tens of microseconds (BASELINE config 1 replayed as hipGraphs) two in flight make every
+        step a host round trip -- event wait, wake-up, graph launch -- which some hosts take 0.2 ms for; eight in flight
+        keep ~0.6 ms of work queued and the step is the GPU's."""
         torch = D.torch_mod()
+        if slots is not None:
+            if slots < 2:
+                raise ValueError("at least two slots")
+            self.SLOTS = int(slots)
         self.taps, self.fs, self.f_off, self.d, self.fs_ch = immutable_taps(taps), float(sample_rate), float(freq_offset), int(decimation), float(fs_channel)
         self.chunk, self.n_frames, self.fmt, self.iq_order = int(chunk), int(n_frames), fmt, iq_order
         self.demod_args = dict(mode=demod_mode, deemph_us=deemph_us, agc_enabled=agc_enabled)

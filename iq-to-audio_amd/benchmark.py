@@ -67,20 +67,42 @@ def run_benchmark(*, seconds: float, sample_rate: float, freq_offset: float, cen
     mode = mode.lower() if isinstance(mode, str) else "nfm"
     LOG.info("Running benchmark: %.2f s at %.2f MS/s, demod=%s, offset %.1f kHz", seconds, sample_rate / 1e6,
              mode.upper(), tone_offset / 1e3)
-    with tempfile.TemporaryDirectory(prefix="iq_bench_") as tmp:
-        wav = Path(tmp) / f"benchmark_fc-{int(center_freq)}Hz.wav"
-        _generate_synthetic_iq(wav, sample_rate, seconds, tone_offset)
-        settings.update(target_freq=float(target_freq), center_freq=float(center_freq), center_freq_source="benchmark",
-                        demod_mode=mode, output_path=Path(tmp) / f"benchmark_audio_{mode}.wav", probe_only=False)
-        settings.pop("in_path", None)
-        t0 = time.perf_counter()
-        result = ProcessingPipeline(ProcessingConfig(in_path=wav, **settings)).run(progress_sink=None)
-        elapsed = time.perf_counter() - t0
+    timing = timed_file_run(seconds=seconds, sample_rate=sample_rate, tone_offset=tone_offset, center_freq=float(center_freq),
+                            target_freq=float(target_freq), settings=settings, mode=mode)
+    elapsed, result = timing["elapsed_s"], timing["result"]
     LOG.info("Benchmark processed %.0f IQ samples in %.3f s (%.2fx realtime).", sample_rate * seconds, elapsed,
              seconds / elapsed if elapsed > 0 else float("inf"))
     LOG.info("Channel decimation %d -> %.1f Hz; audio peak %.2f dBFS.", result.decimation, result.fs_channel,
              20.0 * math.log10(max(result.audio_peak, 1e-6)))
     return 0
+
+
+def timed_file_run(*, seconds: float, sample_rate: float, tone_offset: float, center_freq: float, target_freq: float,
+                   settings: Mapping[str, object] | None = None, mode: str = "nfm", tmp_root: str | None = None, repeats: int = 1,
+                   keep_audio: bool = False) -> dict:
+    """What the reference's ``--benchmark`` times (benchmark.py:104-120): a synthetic PCM16 stereo WAV on disk ->
+    ``ProcessingPipeline.run`` -> 48 kHz PCM16 WAV on disk, wall clock around ``run`` alone (the capture's generation is
+    outside, as in the reference).  ``tmp_root``: where the temporary directory lives (a tmpfs keeps the disk out of
+    the figure).  ``repeats``: run the pipeline that many times on the same file and report every wall time (the first
+    includes plan creation, tap uploads, pinning -- what a one-shot CLI user pays; the later ones what a batch pays).
+    Returns ``{"elapsed_s" (first run), "runs_s", "frames", "realtime_x", "result", "audio_48k" (if keep_audio)}``."""
+    settings = dict(settings or {})
+    with tempfile.TemporaryDirectory(prefix="iq_bench_", dir=tmp_root) as tmp:
+        wav = Path(tmp) / f"benchmark_fc-{int(center_freq)}Hz.wav"
+        _generate_synthetic_iq(wav, sample_rate, seconds, tone_offset)
+        out_path = Path(tmp) / f"benchmark_audio_{mode}.wav"
+        settings.update(target_freq=float(target_freq), center_freq=float(center_freq), center_freq_source="benchmark",
+                        demod_mode=mode, output_path=out_path, probe_only=False)
+        settings.pop("in_path", None)
+        runs, result = [], None
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            result = ProcessingPipeline(ProcessingConfig(in_path=wav, **settings)).run(progress_sink=None)
+            runs.append(time.perf_counter() - t0)
+        audio = iqio.read_wav_pcm16_mono(out_path)[0] if keep_audio else None
+    frames = int(round(sample_rate * seconds))
+    return dict(elapsed_s=runs[0], runs_s=runs, frames=frames, realtime_x=seconds / runs[0] if runs[0] > 0 else float("inf"),
+                result=result, audio_48k=audio)
 
 
 def synthetic_multi_iq_s16(sample_rate: float, seconds: float, carriers, *, noise_std: float = 0.02, seed: int = 42,

@@ -168,32 +168,60 @@ def broadcast_capture(capture, numel: int, dtype, *, src: int = 0, device=None):
     return buf
 
 
-def run_sharded(units: list, stage, *, shared=None, dst: int = 0):
-    """Process independent ``units`` across the ranks of the job and collect their audio on ``dst``.
+class ShardedJob:
+    """Independent ``units`` across the ranks of a job, as an object that can be stepped repeatedly (``bench.py --gpus N
+    --axis channels`` times its steps; :func:`run_sharded` is one step).
 
     ``units``: descriptors of the independent pieces of work -- whole captures (BASELINE config 4) or channels of one
     capture (config 5); every rank takes a contiguous share (:func:`shard_units`).
-    ``stage(my_units, shared) -> [(audio 1-D tensor, peak float), ...]``: the single-GPU hot path for ALL of a rank's
-    units at once (so that the channels of a capture can share one pass over it), one result per unit, in order.
-    ``shared``: ``None`` (capture axis: a unit brings its own capture) or ``dict(tensor=..., numel=..., dtype=...)`` --
-    the capture all units read, present on ``dst`` and replicated to every rank with one broadcast before any unit runs.
-    Returns ``({unit index: np.ndarray}, peak)`` on ``dst`` and ``(None, peak)`` elsewhere; ``peak`` is the max over all
-    units of all ranks.  No collective runs between the broadcast and the final gather."""
-    import torch.distributed as dist
+    ``shared``: ``None`` (capture axis: a unit brings its own capture) or ``dict(tensor=..., numel=..., dtype=...,
+    device=...)`` -- the capture all units read, present on ``dst`` and replicated to every rank with ONE broadcast here,
+    at construction; ``broadcast_s`` is its wall time (max over ranks, after ``sync()`` -- the caller's device
+    synchronise -- and a barrier), reported apart from the steady-state step.
+    ``step(stage)``: ``stage(my_units, shared) -> [(audio 1-D tensor, peak float), ...]`` -- the single-GPU hot path for
+    ALL of a rank's units at once (so that the channels of a capture can share one pass over it), one result per unit,
+    in order -- then the gather of every unit's audio on ``dst``.  No collective runs between the broadcast and that
+    gather.  ref: the reference's sequential loop over ``--ft`` targets, cli.py:683-710."""
 
-    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    common = None
-    if shared is not None:
-        common = broadcast_capture(shared.get("tensor"), int(shared["numel"]), shared["dtype"], src=dst,
-                                   device=shared.get("device"))
-    mine = shard_units(len(units), rank, world)
-    results = list(stage([units[u] for u in mine], common)) if mine else []
-    if len(results) != len(mine):
-        raise RuntimeError(f"stage returned {len(results)} results for {len(mine)} units")
-    audio = [a for a, _ in results]
-    peak = max([float(p) for _, p in results], default=0.0)
-    gathered = gather_audio(audio, mine, len(units), dst=dst)
-    return gathered, max_over_ranks(peak)
+    def __init__(self, units: list, *, shared=None, dst: int = 0, sync=None):
+        import time
+
+        import torch.distributed as dist
+
+        self.units, self.dst = list(units), dst
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        self.common, self.broadcast_s = None, 0.0
+        if shared is not None:
+            t0 = time.perf_counter()
+            self.common = broadcast_capture(shared.get("tensor"), int(shared["numel"]), shared["dtype"], src=dst,
+                                            device=shared.get("device"))
+            if sync is not None:
+                sync()
+            if dist.is_initialized():
+                dist.barrier()
+            self.broadcast_s = max_over_ranks(time.perf_counter() - t0)
+        self.mine = shard_units(len(self.units), self.rank, self.world)
+
+    def my_units(self) -> list:
+        return [self.units[u] for u in self.mine]
+
+    def step(self, stage):
+        """One pass: returns ``({unit index: np.ndarray}, peak)`` on ``dst`` and ``(None, peak)`` elsewhere; ``peak`` is the
+        max over all units of all ranks."""
+        results = list(stage(self.my_units(), self.common)) if self.mine else []
+        if len(results) != len(self.mine):
+            raise RuntimeError(f"stage returned {len(results)} results for {len(self.mine)} units")
+        audio = [a for a, _ in results]
+        peak = max([float(p) for _, p in results], default=0.0)
+        gathered = gather_audio(audio, self.mine, len(self.units), dst=self.dst)
+        return gathered, max_over_ranks(peak)
+
+
+def run_sharded(units: list, stage, *, shared=None, dst: int = 0):
+    """Process independent ``units`` across the ranks of the job and collect their audio on ``dst``: one
+    :class:`ShardedJob` step (see there for ``units``, ``stage`` and ``shared``).
+    Returns ``({unit index: np.ndarray}, peak)`` on ``dst`` and ``(None, peak)`` elsewhere."""
+    return ShardedJob(units, shared=shared, dst=dst).step(stage)
 
 
 class AudioGather:

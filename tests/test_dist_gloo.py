@@ -109,6 +109,43 @@ def test_run_sharded_both_axes_gloo(axis, world, n_units):
     assert ok and peak == n_units - 1 + 0.25
 
 
+def _job_worker(rank, world, port, q, n_units, steps):
+    """bench.py --axis channels: ONE broadcast at construction, then repeated steps (stage + gather), a fence at the end."""
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        units = [dict(k=k, seed=3 + k) for k in range(n_units)]
+        capture = torch.arange(200, dtype=torch.int16) * 7
+        calls = []
+        job = D.ShardedJob(units, shared=dict(tensor=capture if rank == 0 else None, numel=200, dtype=torch.int16, device=torch.device("cpu")),
+                           sync=lambda: calls.append("sync"))
+        assert calls == ["sync"] and job.broadcast_s >= 0.0
+        assert torch.equal(job.common, capture)  # every rank holds the whole capture after the one broadcast
+        assert [u["k"] for u in job.my_units()] == D.shard_units(n_units, rank, world)
+        outs = []
+        for i in range(steps):
+            def stage(mine, shared, i=i):
+                return [(a + i, p) for a, p in _stub_stage(mine, shared)]
+            outs.append(job.step(stage))
+        D.fence(None)
+        if rank == 0:
+            want = _stub_stage(units, capture)
+            ok = all(sorted(got) == list(range(n_units)) and all(np.array_equal(got[u], (want[u][0] + i).numpy()) for u in got)
+                     for i, (got, _) in enumerate(outs))
+            q.put((ok, outs[-1][1]))
+        else:
+            assert all(got is None for got, _ in outs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_units", [(2, 5), (3, 40)])
+def test_sharded_job_steps_gloo(world, n_units):
+    """dist.ShardedJob -- what ``bench.py --gpus N --axis channels`` constructs and steps: the capture is broadcast once,
+    every step gathers every unit's audio on rank 0 (40 units over 3 ranks: config 5's channel count on an odd world)."""
+    ok, peak = _spawn(_job_worker, world, n_units, 3)
+    assert ok and peak == n_units - 1 + 0.25
+
+
 def test_run_sharded_without_process_group():
     units = [dict(k=k, seed=3 + k) for k in range(3)]
     got, peak = D.run_sharded(units, _stub_stage)

@@ -71,7 +71,7 @@ def oracle_ssb_f64_chunks(z, chunk_lens, mode, agc=True):
     return np.concatenate(out) if out else np.empty(0, np.float32)
 
 
-def ssb_agc_evidence(label, z_gpu, audio_gpu, z_ref, audio_ref, chunk_lens, mode, fs_ch, z_tol, strict_replay=False):
+def ssb_agc_evidence(label, z_gpu, audio_gpu, z_ref, audio_ref, chunk_lens, mode, fs_ch, z_tol, strict_replay=False, e2e_max=None):
     """SSB with AGC on: localise the GPU-vs-oracle difference BY CAUSE.
 
     It cannot be localised in TIME: the gain carries every near-zero sample's error for ~1000 samples, so an input
@@ -114,6 +114,8 @@ def ssb_agc_evidence(label, z_gpu, audio_gpu, z_ref, audio_ref, chunk_lens, mode
     else:
         assert e_rms < 1e-3 and frac > 0.9, (label, "replay", e_rms, frac)
     assert err < 2.0 * kappa + 2e-5, (label, "end-to-end", err, kappa)
+    if e2e_max is not None:  # what is measured at the product's precision for this case, with margin
+        assert err < e2e_max, (label, "end-to-end (absolute)", err, e2e_max)
     return dict(dz=dz, logic_max=float(logic.max()), replay_rms=e_rms, replay_median=med, replay_frac=frac, err=err, kappa=kappa)
 
 
@@ -164,8 +166,8 @@ def test_ssb_agc_same_input_full_c1(A, golden):
         assert got.size == want.audio.size == int(g[mode + "_n"]) == 480_770
         lens = chunk_lens_for(n, chunk, d, n_dec)
         assert len(lens) == 12
-        ev = ssb_agc_evidence(f"C1 {mode}", z_gpu, got, want.decimated, want.audio, lens, mode, fs_ch, z_tol=2e-5,
-                              strict_replay=True)
+        ev = ssb_agc_evidence(f"C1 {mode}", z_gpu, got, want.decimated, want.audio, lens, mode, fs_ch, z_tol=2e-7,
+                              strict_replay=True, e2e_max=1.5e-2)  # (6.5e-3 measured; 3.4e-2 at "fast")
         assert ev["dz"] < 2e-7  # ("full": the per-lane kernel, taps + their residue as chained passes; "fast" measured 2.0e-6)
         assert ch._kernel.last_kernel == "k_channelize_mfma_s16"
         assert abs(rms(got) - float(g[mode + "_rms"])) < 0.01 * float(g[mode + "_rms"])
@@ -257,7 +259,7 @@ def test_config3_workload_five_mixed_targets_agc_on(A, tmp_path):
         if mode in ("usb", "lsb"):
             lens = chunk_lens_for(n, chunk, 208, got.size)
             ev = ssb_agc_evidence(f"C3 {mode} {off:+.0f} Hz", z_gpu, got, want.decimated, want.audio, lens, mode,
-                                  want.fs_channel, z_tol=5e-5)
+                                  want.fs_channel, z_tol=3e-7, e2e_max=5e-4)  # (1.1e-4 / 1.7e-4 measured; 1.8e-2 / 7.7e-2 at "fast")
             assert ev["dz"] < 3e-7, (mode, ev["dz"])  # ("fast" measured 3.2e-6)
             assert rms(want.audio) > 0.05
             continue
