@@ -539,7 +539,7 @@ def main_channel_axis(args, json_fd: int) -> None:
 
     def stage(units, capture):
         res = runner.collect(runner.submit(raw, enclosing=buf, lead_frames=0))
-        return [(torch.from_numpy(r["pcm_host"].numpy().copy()).to(D.device()), r["demod"].peak) for r in res]
+        return [(r["pcm"], r["demod"].peak) for r in res]  # (device PCM16, valid until this slot's next capture: gathered right away)
 
     steps = args.steps if args.steps != 1000 else 5  # (the defaults of the capture axis are sized for 0.7 ms steps)
     warm = args.warmup if args.warmup != 100 else 2

@@ -113,8 +113,9 @@ class ResidentCaptureRunner:
         """What the precision guard asks for, given a probe that has been read (``power``, ``wideband_rms`` set)."""
         if not self._guarded or probe is None:
             return self.base_precision
+        memo = self.__dict__.setdefault("_guard_memo", {}).setdefault(sign, {})
         return pick_precision(self._kernel_for(sign), self.base_precision, self.demod_args["mode"], probe.power, probe.wideband_rms,
-                              self.guard)
+                              self.guard, memo)
 
     def _chain(self, raw_dev, slot, sign: int, events=None, halo=None, resident: bool = False, probe=None, precision: str | None = None):
         """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
@@ -316,7 +317,9 @@ class ResidentCaptureRunner:
             self._next += 1
         entry["dem"].chunk_sumsq = entry["dem"].chunk_sumsq[-1:]  # (a replay re-runs the same demodulator call)
         entry["graph"].replay()
-        done = torch.cuda.Event()
+        done = entry.get("done_event")  # (one event per graph: its slot's previous capture was collected above)
+        if done is None:
+            done = entry["done_event"] = torch.cuda.Event()
         done.record()
         ticket = dict(chan=entry["chan"], dem=entry["dem"], pcm=entry["pcm"], done=done, tail_done=done, kernel=entry["kernel"],
                       slot=slot, egress_queued=True, resident=False, probe=None, graph_probe=entry["probe"],
@@ -477,8 +480,9 @@ class ResidentBankRunner:
     def _needed_precision(self, spec, probe, sign: int) -> str:
         if probe is None or not self._guarded(spec):
             return spec["base_precision"]
+        memo = spec.setdefault("_guard_memo", {}).setdefault(sign, {})
         return pick_precision(lambda name: self._channelizer(spec, sign, name)._kernel, spec["base_precision"], spec["demod_mode"],
-                              probe.power, probe.wideband_rms, self.guard)
+                              probe.power, probe.wideband_rms, self.guard, memo)
 
     def _finish_target(self, per, raw_unused=None) -> None:
         """Demodulator + writer clip, 48 kHz PCM16, copy to the host: for one target's z."""
@@ -487,6 +491,7 @@ class ResidentBankRunner:
         dem.process(per["z"], self.starts, per["audio"])
         pcm = self.rs.process(per["audio"], want="pcm16")
         per["pcm_host"].copy_(pcm, non_blocking=True)
+        per["pcm"] = pcm  # (the device copy: what an N-GPU job hands to the RCCL gather; valid until this slot's next capture)
 
     def submit(self, raw_dev, enclosing=None, lead_frames: int = 0, events=None) -> dict:
         """Queue one capture; ``events``: optional pair of torch events recorded around the channelizer's pass."""
@@ -585,7 +590,7 @@ class ResidentBankRunner:
         ticket["raw"] = None
         if slot["busy"] is ticket:
             slot["busy"] = None
-        ticket["result"] = [dict(pcm_host=per["pcm_host"], audio=per["audio"], z=per["z"], sign=int(sg), demod=per["dem"], precision=pr)
+        ticket["result"] = [dict(pcm_host=per["pcm_host"], pcm=per.get("pcm"), audio=per["audio"], z=per["z"], sign=int(sg), demod=per["dem"], precision=pr)
                             for per, sg, pr in zip(slot["per"], ticket["signs"], ticket["precisions"])]
         return ticket["result"]
 
@@ -614,7 +619,7 @@ def demodulate_sharded(targets: list, *, sample_rate: float, n_frames: int, axis
     def run_bank(specs, raw_dev):
         runner = ResidentBankRunner(specs, sample_rate=sample_rate, n_frames=n_frames, chunk_size=chunk_size, fmt=fmt, iq_order=iq_order)
         res = runner.collect(runner.submit(raw_dev))
-        return [(torch.from_numpy(r["pcm_host"].numpy().copy()).to(raw_dev.device), r["demod"].peak) for r in res]
+        return [(r["pcm"].clone(), r["demod"].peak) for r in res]  # (device PCM16: the gather is RCCL's)
 
     if axis == "channels":
         dtype = {"s16": torch.int16, "u8": torch.uint8, "f32": torch.float32}[fmt]

@@ -277,16 +277,25 @@ __global__ __launch_bounds__(1024) void k_mean_power_small(const float2 *z, long
 // (I and Q alike; uint8 minus 128), estimated from up to 1024 x `rounds` 16-byte vectors spread evenly over the range.
 // One workgroup, fixed order, the result WRITTEN (mapped pinned host memory is fine).
 template <int FMT>
-__global__ __launch_bounds__(1024) void k_raw_level(const uint4 *raw, long long n_vec, long long step, int rounds, double *out)
+__global__ __launch_bounds__(1024) void k_raw_level(const uint4 *raw, long long n_vec, long long step, double *out)
 {
+    constexpr int ROUNDS = 8;
     __shared__ double s_w[16];
     double acc = 0.0;
     long long cnt = 0;
-    for (int r = 0; r < rounds; ++r) {
+    // all loads first (independent cache lines, far apart: one round trip instead of ROUNDS), then the arithmetic
+    uint4 v[ROUNDS];
+    bool ok[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
         const long long i = (static_cast<long long>(r) * 1024 + threadIdx.x) * step;
-        if (i >= n_vec) break;
-        const uint4 v = raw[i];
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        ok[r] = i < n_vec;
+        v[r] = ok[r] ? raw[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (!ok[r]) continue;
+        const unsigned w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (FMT == IQA_FMT_S16) {
@@ -905,9 +914,9 @@ extern "C" int iqa_raw_level(int32_t fmt, const void *raw_dev, int64_t n_values,
     hipStream_t s = as_stream(stream);
     double *out = static_cast<double *>(mean_square_out);
     const uint4 *raw = static_cast<const uint4 *>(raw_dev);
-    if (fmt == IQA_FMT_S16) hipLaunchKernelGGL(k_raw_level<IQA_FMT_S16>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, ROUNDS, out);
-    else if (fmt == IQA_FMT_U8) hipLaunchKernelGGL(k_raw_level<IQA_FMT_U8>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, ROUNDS, out);
-    else hipLaunchKernelGGL(k_raw_level<IQA_FMT_F32>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, ROUNDS, out);
+    if (fmt == IQA_FMT_S16) hipLaunchKernelGGL(k_raw_level<IQA_FMT_S16>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, out);
+    else if (fmt == IQA_FMT_U8) hipLaunchKernelGGL(k_raw_level<IQA_FMT_U8>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, out);
+    else hipLaunchKernelGGL(k_raw_level<IQA_FMT_F32>, dim3(1), dim3(1024), 0, s, raw, n_vec, step, out);
     return check_launch("k_raw_level");
 }
 

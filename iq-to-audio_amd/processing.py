@@ -378,7 +378,7 @@ class _ChannelKernel:
 # built and cost ~0.5 ms of host NumPy per configuration: a batch of captures with the same settings, the two
 # probes of choose_mix_sign and the channelizer that follows them all share them through this small LRU.
 _KERNEL_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
-_KERNEL_CACHE_MAX = 16
+_KERNEL_CACHE_MAX = 192  # (BASELINE config 5 on one GPU: 40 channels x (two probe signs + the channel) = 120 kernels, ~0.5 MB of device taps each)
 _KERNEL_CACHE_LOCK = threading.Lock()
 
 
@@ -929,10 +929,13 @@ def wideband_rms_from(mean_square: float, fmt: str) -> float:
 PRECISION_GUARD = 1000.0
 
 
-def pick_precision(kernel_for, base: str, demod_mode: str | None, channel_power, wideband_rms, guard: float | None = None) -> str:
+def pick_precision(kernel_for, base: str, demod_mode: str | None, channel_power, wideband_rms, guard: float | None = None,
+                   memo: dict | None = None) -> str:
     """The cheapest precision, not below ``base``, at which a channel of mean power ``channel_power`` (|z|^2, from the
     mixer-sign probe) in a capture of wideband RMS ``wideband_rms`` keeps the 1e-4 audio bar.  Only NFM is guarded (AM
-    and SSB do not divide by |z|).  ``kernel_for(precision)`` returns the planned ``_ChannelKernel``."""
+    and SSB do not divide by |z|).  ``kernel_for(precision)`` returns the planned ``_ChannelKernel``; ``memo`` (a dict the
+    caller keeps per channel and sign) remembers each precision's (tap-rounding norm, floor), so that a batch asks the
+    kernels once, not once per capture."""
     levels = _ChannelKernel.PRECISIONS
     guard = PRECISION_GUARD if guard is None else guard
     if not guard or channel_power is None or wideband_rms is None or (demod_mode or "").lower() not in ("nfm", "fm"):
@@ -941,10 +944,21 @@ def pick_precision(kernel_for, base: str, demod_mode: str | None, channel_power,
     for name in levels[levels.index(base):]:
         if name == "float32":
             break
-        k = kernel_for(name)
-        if k.precision != name:  # (this capture format has no such kernel: uint8 "full", float32 anything)
+        known = None if memo is None else memo.get(name)
+        if known is None:
+            k = kernel_for(name)
+            if k.precision != name:  # (this capture format has no such kernel: uint8 "full", float32 anything)
+                known = False
+            elif not k._mfma_ok:
+                known = (0.0, 0.0)
+            else:
+                mp = k._ensure_mfma()
+                known = (float(mp.err_norm), float(mp.floor_rms))
+            if memo is not None:
+                memo[name] = known
+        if known is False:
             continue
-        err = k.fixed_point_error_rms(wideband_rms)
+        err = math.hypot(known[0] * wideband_rms, known[1])
         if err <= 0.0 or level >= guard * err:
             return name
     return "float32"
@@ -1301,8 +1315,27 @@ class _BlockStager:
         self.pending = None  # (thread, slot, lo, hi)
         self.slot = 0
 
+    #: helper threads of one block copy (file mapping -> pinned buffer): a single memcpy moves ~2.7 GB/s on the GPU boxes'
+    #: hosts, which made the FILE the bottleneck of a file -> WAV run (10 s @ 10 MS/s: 0.148 s, of which ~0.1 s this copy)
+    copy_threads = 8
+
     def _fill(self, slot: int, lo: int, hi: int) -> None:
-        np.copyto(self.bufs[slot].numpy()[: 2 * (hi - lo)], self.frames[2 * lo : 2 * hi])
+        import threading
+
+        dst = self.bufs[slot].numpy()[: 2 * (hi - lo)]
+        src = self.frames[2 * lo : 2 * hi]
+        parts = min(int(self.copy_threads), max(1, dst.size // (1 << 22)))  # (NumPy copies release the GIL)
+        if parts <= 1:
+            np.copyto(dst, src)
+            return
+        cuts = [dst.size * i // parts for i in range(parts + 1)]
+        workers = [threading.Thread(target=np.copyto, args=(dst[a:b], src[a:b]), name="iq-stager-copy", daemon=True)
+                   for a, b in zip(cuts[1:-1], cuts[2:])]
+        for w in workers:
+            w.start()
+        np.copyto(dst[: cuts[1]], src[: cuts[1]])
+        for w in workers:
+            w.join()
 
     def prefetch(self, lo: int, hi: int) -> None:
         import threading
