@@ -227,6 +227,21 @@ def main() -> None:
             full["z_meanabs"] = np.float64(np.mean(np.abs(r["z"])))
     np.savez_compressed(GOLD / "c1_full_scalars.npz", **full)
 
+    # ---- (v) pass-through encoders (--demod none): the reference's own _encode_iq_raw (processing.py:527-539) --------
+    rng = np.random.default_rng(23)
+    z = (rng.normal(scale=0.4, size=6000) + 1j * rng.normal(scale=0.4, size=6000)).astype(np.complex64)
+    edges = np.array([1.0, -1.0, 0.999969, 0.99997, 0.9999695, 1.5, -1.5, 0.0, -0.0, 1e-9, -1e-9, 0.5 / 32767.0, -0.5 / 32767.0,
+                      1.0 / 127.5, 0.5 / 127.5, -0.5 / 127.5, 1.5 / 127.5, 2.5 / 127.5, 0.25, -0.25, 32766.5 / 32767.0], dtype=np.float32)
+    z[: edges.size] = edges + 1j * edges[::-1]
+    # values that sit exactly on the uint8 rounding boundaries ((x + 1) * 127.5 = k + 0.5: np.round is half-to-even)
+    ks = np.arange(0, 255, dtype=np.float64)
+    ties = ((ks + 0.5) / 127.5 - 1.0).astype(np.float32)
+    z[100 : 100 + ties.size] = ties + 1j * ties[::-1]
+    enc = {"z": z}
+    for codec, dt in (("pcm_s16le", "<i2"), ("pcm_u8", np.uint8), ("pcm_f32le", "<f4")):
+        enc[codec] = np.frombuffer(proc._encode_iq_raw(z, codec), dtype=dt).copy()
+    np.savez_compressed(GOLD / "encode_raw.npz", **enc)
+
     import scipy
 
     (GOLD / "README.md").write_text(

@@ -329,6 +329,25 @@ def test_cli_argument_surface():
         assert exc.value.code == 2
 
 
+def test_pass_through_encoders_against_the_reference_fixture():
+    """iqio.encode_iq_slice (headerless containers) against outputs of the reference's OWN ``_encode_iq_raw``
+    (processing.py:527-539; tests/golden/encode_raw.npz, generated by oracle/gen_golden.py): int16 = clip to
+    [-1, 0.999969], x 32767, truncated toward zero; uint8 = round-half-even((clip(x, +-1) + 1) * 127.5) -- including the
+    +-1 edges, out-of-range values, signed zeros and every value that sits exactly on a uint8 rounding tie."""
+    g = np.load(Path(__file__).parent / "golden" / "encode_raw.npz")
+    z = g["z"]
+    assert z.dtype == np.complex64 and z.size == 6000
+    for codec in ("pcm_s16le", "pcm_u8", "pcm_f32le"):
+        got = iqio.encode_iq_slice(z, codec, "raw")
+        want = g[codec]
+        assert got.dtype == want.dtype and got.shape == want.shape == (12000,)
+        np.testing.assert_array_equal(got, want)
+    assert g["pcm_s16le"].max() == 32765 and g["pcm_s16le"].min() == -32767  # (0.999969 * 32767 truncates to 32765)
+    assert g["pcm_u8"].max() == 255 and g["pcm_u8"].min() == 0
+    with pytest.raises(ValueError):
+        iqio.encode_iq_slice(z, "pcm_s24le", "raw")
+
+
 @pytest.mark.parametrize("fs,bw,d", [(10e6, 12_500.0, 104), (20e6, 12_500.0, 208), (20e6, 2_800.0, 208), (5e6, 12_500.0, 52)])
 def test_mfma_plan_quantisation_is_exact_and_overflow_proof(fs, bw, d):
     """dsp_plan.plan_mfma: T = 256*q1 + q2 with both bytes signed reproduces the quantised taps exactly, the per-pass
