@@ -366,6 +366,19 @@ int iqa_trickle_copy(const void *src_dev, void *dst_mapped, int64_t nbytes, int3
  * processing.py:268-279, with ffmpeg's f32le -> float being the identity).  f32_dev 16-byte aligned. */
 int iqa_f32_to_s16_exact(const void *f32_dev, int64_t n_values, void *s16_out_dev, void *flag_dev, void *stream);
 
+/* A float32 capture as TWO int16 planes, x = 2^shift (hi + lo / 32768) / 32768 (hi = rint(2^(15-shift) x), |lo| <= 16384),
+ * exact to 2^(shift-31) of full scale: the linear channel filter then gives z = 2^shift (z(hi) + 2^-15 z(lo)) from two
+ * passes of the int16 matrix-core channelizers -- a float capture that is NOT on the 2^-15 grid (RTL-SDR's
+ * (u - 127.5) / 127.5, k / 32767, resampled recordings) leaves the float32 VALU kernel too.  shift: headroom in bits (0:
+ * values within [-1, 1 - 2^-16]; 1: within +-2; ...; the caller picks it from the warm-up block's largest value).
+ * *flag_dev (int32, caller-zeroed) |= 1 when a value does not fit (or is a NaN: the planes are then not the capture),
+ * |= 2 when some lo != 0 (otherwise hi alone IS the capture: iqa_f32_to_s16_exact's case at shift 0).  f32_dev 16-byte
+ * aligned, outputs 8-byte aligned, n_values each.
+ * ref: the float32 ingest of IQReader (ffmpeg hands the reference everything as f32le, processing.py:113-158, 268-279;
+ * input_formats.py:62-64, 86-91). */
+int iqa_f32_split_s16(const void *f32_dev, int64_t n_values, int32_t shift, void *hi_out_dev, void *lo_out_dev, void *flag_dev,
+                      void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Spectrum / waterfall                                   *
  * ------------------------------------------------------------------------- */

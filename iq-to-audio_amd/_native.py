@@ -110,6 +110,7 @@ _SIGNATURES = {
     "iqa_float_to_pcm16": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "iqa_trickle_copy": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "iqa_f32_to_s16_exact": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "iqa_f32_split_s16": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iqa_psd_frames": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                       c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iqa_pair_average_rows": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -145,6 +145,67 @@ __global__ __launch_bounds__(256) void k_f32_to_s16_exact(const float4 *in, long
 }
 }  // namespace iqa
 
+// float32 capture -> TWO int16 planes: x = 2^shift (hi + lo / 32768) / 32768 with hi = rint(S x), lo = rint(32768 (S x - hi)),
+// S = 2^(15 - shift), |lo| <= 16384 -- exact to 2^(shift - 31) of full scale (every step but the last rint is exact in float32: multiplications by
+// powers of two, a difference of neighbours).  The channel filter is linear, so the matrix-core int16 channelizers give
+// z = z(hi) + 2^-15 z(lo): what SDR software writes as (u - 127.5) / 127.5 or k / 32767, resampled or filtered recordings,
+// any float capture within +-1.  flag bit 0: a value outside [-1, 1 - 2^-16] or a NaN (not representable: the caller
+// stays on the float32 kernel); bit 1: some lo != 0 (otherwise the capture IS an int16 capture and one pass suffices).
+namespace iqa {
+__global__ __launch_bounds__(256) void k_f32_split_s16(const float4 *in, long long n4, const float *in_tail, int n_tail, float scale,
+                                                       short *hi_out, short *lo_out, int *flag)
+{
+    int bits = 0;
+    auto conv = [&](float x, short &hi, short &lo) {
+        const float sc = x * scale;  // a power of two: exact
+        const float h = rintf(sc);
+        if (!(h >= -32768.0f && h <= 32767.0f)) bits |= 1;  // (NaN fails both comparisons)
+        const float r = (sc - h) * 32768.0f;  // |sc - h| <= 0.5, exact; times a power of two, exact
+        const float l = rintf(r);
+        if (l != 0.0f) bits |= 2;
+        hi = static_cast<short>(fminf(fmaxf(h, -32768.0f), 32767.0f));
+        lo = static_cast<short>(fminf(fmaxf(l, -16384.0f), 16384.0f));
+    };
+    const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = in[i];
+        short4 h, l;
+        conv(v.x, h.x, l.x);
+        conv(v.y, h.y, l.y);
+        conv(v.z, h.z, l.z);
+        conv(v.w, h.w, l.w);
+        reinterpret_cast<short4 *>(hi_out)[i] = h;
+        reinterpret_cast<short4 *>(lo_out)[i] = l;
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < n_tail) {
+        short h, l;
+        conv(in_tail[threadIdx.x], h, l);
+        hi_out[4 * n4 + threadIdx.x] = h;
+        lo_out[4 * n4 + threadIdx.x] = l;
+    }
+    const unsigned long long b0 = __ballot(bits & 1), b1 = __ballot(bits & 2);
+    if ((b0 | b1) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, (b0 ? 1 : 0) | (b1 ? 2 : 0));
+}
+}  // namespace iqa
+
+extern "C" int iqa_f32_split_s16(const void *f32_dev, int64_t n_values, int32_t shift, void *hi_out_dev, void *lo_out_dev, void *flag_dev,
+                                 void *stream)
+{
+    if (n_values < 0) return fail_inval("negative length");
+    if (shift < 0 || shift > 15) return fail_inval("shift must be in 0..15");
+    if (n_values == 0) return IQA_OK;
+    if (!f32_dev || !hi_out_dev || !lo_out_dev || !flag_dev) return fail_inval("NULL device pointer");
+    if ((reinterpret_cast<uintptr_t>(f32_dev) & 15) || (reinterpret_cast<uintptr_t>(hi_out_dev) & 7) || (reinterpret_cast<uintptr_t>(lo_out_dev) & 7))
+        return fail_inval("input must be 16-byte aligned, outputs 8-byte aligned");
+    const long long n4 = n_values / 4;
+    const int n_tail = static_cast<int>(n_values - 4 * n4);
+    const float *tail = static_cast<const float *>(f32_dev) + 4 * n4;
+    const unsigned blocks = static_cast<unsigned>(std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 256 * 16));
+    hipLaunchKernelGGL(iqa::k_f32_split_s16, dim3(blocks), dim3(256), 0, iqa::as_stream(stream), static_cast<const float4 *>(f32_dev), n4, tail,
+                       n_tail, std::ldexp(1.0f, 15 - shift), static_cast<short *>(hi_out_dev), static_cast<short *>(lo_out_dev), static_cast<int *>(flag_dev));
+    return iqa::check_launch("k_f32_split_s16");
+}
+
 extern "C" int iqa_f32_to_s16_exact(const void *f32_dev, int64_t n_values, void *s16_out_dev, void *flag_dev, void *stream)
 {
     if (n_values < 0) return fail_inval("negative length");

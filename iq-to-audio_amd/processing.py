@@ -1692,12 +1692,24 @@ class MultiChannelPipeline:
             # int16 / 12-bit / int8 ADC samples): each block is re-packed to int16 on the device, checked value by value
             # (iqa_f32_to_s16_exact), and takes the matrix-core channelizers; the first block that is NOT of that form
             # switches the rest of the run to the float32 kernel (whose state has been carried along all the time).
-            banks16 = None
+            # Every other float32 capture within the planes' range (RTL-SDR's (u - 127.5) / 127.5, k / 32767, resampled or
+            # filtered recordings) is TWO int16 planes, x = 2^shift (hi + lo / 32768) / 32768 exactly to 2^(shift - 31)
+            # (iqa_f32_split_s16), and the filter is linear: z = 2^shift (z(hi) + 2^-15 z(lo)), two passes of the int16
+            # channelizers (the second at "fast": its input is 2^-15 of the first's).
+            banks16 = banks16_lo = None
+            shift16 = 0
             if info.fmt == "f32" and self.owners[0].f32_integer_path:
                 banks16 = [(ChannelBank([t._channelizer(t.mix_sign, precision=t.precision, fmt="s16") for t in members]), members)
                            for _, members in banks]
+                banks16_lo = [(ChannelBank([t._channelizer(t.mix_sign, precision="fast", fmt="s16") for t in members]), members)
+                              for _, members in banks]
                 flag16 = D.zeros(1, "int32")
-            self.integer_blocks = 0  # blocks of a float32 capture that ran as int16
+                # headroom from the warm-up block's largest value (a later block that exceeds it falls back to the float32 kernel)
+                top = float(warm.view(D.torch_mod().float32).abs().max().item())
+                while shift16 < 8 and top * 2.0 ** (15 - shift16) > 32767.0:
+                    shift16 += 1
+            self.integer_blocks = 0  # blocks of a float32 capture that ran as int16 (one plane)
+            self.split_blocks = 0  # blocks of a float32 capture that ran as two int16 planes
             done = 0
             while done < total:
                 _check_cancel(f"block at frame {done}")
@@ -1708,18 +1720,33 @@ class MultiChannelPipeline:
                 n = hi - done
                 tracker.advance("ingest", float(n))
                 tracker.status(f"channel @ {done}")
-                raw16 = None
+                raw16 = raw16_lo = None
+                lo_needed = False
                 if banks16 is not None:
-                    raw16 = D.empty(2 * n, "int16")
-                    N.call("iqa_f32_to_s16_exact", N.ptr(raw), c_int64(2 * n), N.ptr(raw16), N.ptr(flag16), N.stream_ptr())
-                    if int(flag16.item()):  # (a host read per 64 Mi-frame block)
-                        LOG.info("float32 capture is not an integer capture from frame %d on: float32 channelizer.", done)
-                        banks16 = raw16 = None
+                    raw16, raw16_lo = D.empty(2 * n, "int16"), D.empty(2 * n, "int16")
+                    flag16.zero_()
+                    N.call("iqa_f32_split_s16", N.ptr(raw), c_int64(2 * n), c_int32(shift16), N.ptr(raw16), N.ptr(raw16_lo), N.ptr(flag16),
+                           N.stream_ptr())
+                    bits = int(flag16.item())  # (a host read per 64 Mi-frame block)
+                    if bits & 1:
+                        LOG.info("float32 capture leaves the range of the int16 planes (shift %d) at frame %d: float32 channelizer.",
+                                 shift16, done)
+                        banks16 = banks16_lo = raw16 = raw16_lo = None
+                    else:
+                        lo_needed = bool(bits & 2)
                 for bi, (bank, members) in enumerate(banks):  # one pass over the block per decimation, all its channels at once
                     for t in members:
                         t.before_block(done, n, chunk)
                     if raw16 is not None:
                         zs = banks16[bi][0].process(raw16)
+                        if lo_needed:
+                            zs_lo = banks16_lo[bi][0].process(raw16_lo)
+                            zs = [z.add_(zl, alpha=2.0 ** -15) for z, zl in zip(zs, zs_lo)]
+                        else:  # (nothing in the low plane of this block: its channelizers' history and position move along)
+                            for c in banks16_lo[bi][0].chans:
+                                c._advance(raw16_lo, n)
+                        if shift16:
+                            zs = [z.mul_(2.0 ** shift16) for z in zs]
                         x32, _ = _as_frames(raw, "f32")
                         for c in bank.chans:  # the float32 channelizers' state moves along (history, position)
                             c._advance(x32, n)
@@ -1728,7 +1755,8 @@ class MultiChannelPipeline:
                     for t, z in zip(members, zs):
                         t.after_block(z, tracker)
                 if raw16 is not None:
-                    self.integer_blocks += 1
+                    self.integer_blocks += 0 if lo_needed else 1
+                    self.split_blocks += 1 if lo_needed else 0
                 for bi, (_, members) in enumerate(banks):
                     for ti, t in enumerate(members):  # (for finish(): which kernel produced this target's last block)
                         t.chan16_kernel = banks16[bi][0].chans[ti]._kernel.last_kernel if raw16 is not None else None

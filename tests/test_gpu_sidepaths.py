@@ -212,23 +212,60 @@ def test_float32_capture_that_is_an_integer_capture_takes_the_matrix_cores(A, tm
     assert outs["f32"][1] == outs["s16"][1] == "k_channelize_mfma_s16_ring"
     assert (outs["s16"][2], outs["f32"][2]) == (0, 4)
     assert torch.equal(outs["f32"][0], outs["s16"][0])
-    # one value off the 2^-15 grid in the last block
-    bent = f32.copy()
-    bent[2 * 3_500_000 + 1] += np.float32(1e-6)
-    path = tmp_path / f"bent_{int(FC)}Hz.cf32"
-    path.write_bytes(bent.tobytes())
-    pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=path, target_freq=FC + F_OFF, input_sample_rate=fs, output_path=tmp_path / "b.wav"))
-    pipe.block_frames_target = 1_048_576
-    pipe.keep_channel_audio = True
-    pipe.run()
-    assert pipe._multi.integer_blocks == 3 and pipe.channelizer_kernel == "k_channelize_v1"
-    want = O.run_chain(bent, sample_rate=fs, freq_offset=F_OFF, fmt="f32", keep_decimated=False)
-    got = pipe.audio_fs_channel.cpu().numpy()
-    assert got.size == want.audio.size
-    assert float(np.sqrt(np.mean((got - want.audio) ** 2))) < 2e-5
+    # one value off the 2^-15 grid in the last block: that block runs as TWO int16 planes (hi + lo / 32768), still on the
+    # matrix cores; one value outside +-1 in the last block: that one the planes cannot hold -> float32 kernel, state carried
+    for label, delta, blocks, kernel in (("bent", np.float32(1e-6), (3, 1), "k_channelize_mfma_s16_ring"),
+                                         ("over", np.float32(1.5), (3, 0), "k_channelize_v1")):
+        bent = f32.copy()
+        bent[2 * 3_500_000 + 1] += delta
+        path = tmp_path / f"{label}_{int(FC)}Hz.cf32"
+        path.write_bytes(bent.tobytes())
+        pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=path, target_freq=FC + F_OFF, input_sample_rate=fs, output_path=tmp_path / "b.wav"))
+        pipe.block_frames_target = 1_048_576
+        pipe.keep_channel_audio = True
+        pipe.run()
+        assert (pipe._multi.integer_blocks, pipe._multi.split_blocks) == blocks and pipe.channelizer_kernel == kernel, label
+        want = O.run_chain(bent, sample_rate=fs, freq_offset=F_OFF, fmt="f32", keep_decimated=False)
+        got = pipe.audio_fs_channel.cpu().numpy()
+        assert got.size == want.audio.size
+        assert float(np.sqrt(np.mean((got - want.audio) ** 2))) < 2e-5, label
     # and the switch itself
     pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=tmp_path / f"cap_{int(FC)}Hz.cf32", target_freq=FC + F_OFF,
                                                    input_sample_rate=fs, output_path=tmp_path / "off.wav"))
     pipe.f32_integer_path = False
     pipe.run()
     assert pipe._multi.integer_blocks == 0 and pipe.channelizer_kernel == "k_channelize_v1"
+
+
+@pytest.mark.parametrize("grid", ["rtlsdr", "k32767", "float"])
+def test_fractional_float32_captures_run_as_two_int16_planes(A, tmp_path, grid):
+    """cf32 captures that are NOT on the 2^-15 grid -- RTL-SDR's (u - 127.5) / 127.5 (reaches +-1: one bit of headroom),
+    int16 samples scaled by 1 / 32767, and genuinely continuous floats -- run as two int16 planes on the matrix-core
+    channelizers (iqa_f32_split_s16: x = 2^shift (hi + lo / 32768) / 32768, z = 2^shift (z(hi) + 2^-15 z(lo))) instead
+    of the float32 VALU kernel: NFM audio within 2e-5 RMS of the oracle's float32 ingest of the very same values, two
+    device blocks (the low plane's channelizers carry their own history)."""
+    fs, secs = 2.5e6, 2 * 1_048_576 / 2.5e6 + 0.11
+    s16 = O.synth_capture_s16(FS, secs, F_OFF).reshape(-1)
+    if grid == "rtlsdr":
+        u8 = np.clip((s16.astype(np.int32) >> 8) + 128, 0, 255).astype(np.uint8)
+        u8[:2] = (255, 0)  # the grid's end points: +1.0 and -1.0
+        f32 = ((u8.astype(np.float32) - np.float32(127.5)) / np.float32(127.5)).astype(np.float32)
+    elif grid == "k32767":
+        f32 = (s16.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    else:
+        rng = np.random.default_rng(17)
+        f32 = (s16.astype(np.float64) / 32768.0 * 0.83 + rng.normal(scale=1e-5, size=s16.size)).astype(np.float32)
+    path = tmp_path / f"frac_{int(FC)}Hz.cf32"
+    path.write_bytes(f32.tobytes())
+    pipe = A.ProcessingPipeline(A.ProcessingConfig(in_path=path, target_freq=FC + F_OFF, input_sample_rate=fs, output_path=tmp_path / "f.wav"))
+    pipe.block_frames_target = 1_048_576
+    pipe.keep_channel_audio = True
+    res = pipe.run()
+    n_blocks = -(-(f32.size // 2) // 1_048_576)
+    assert (pipe._multi.integer_blocks, pipe._multi.split_blocks) == (0, n_blocks) and pipe.channelizer_kernel == "k_channelize_mfma_s16_ring"
+    want = O.run_chain(f32, sample_rate=fs, freq_offset=F_OFF, fmt="f32", keep_decimated=False)
+    got = pipe.audio_fs_channel.cpu().numpy()
+    assert got.size == want.audio.size and res.mix_sign == want.mix_sign
+    err = float(np.sqrt(np.mean((got - want.audio) ** 2)))
+    print(f"fractional float32 capture ({grid}): {n_blocks} blocks as two int16 planes, audio rms err {err:.2e}")
+    assert err < 2e-5, (grid, err)
