@@ -244,7 +244,7 @@ def test_fractional_float32_captures_run_as_two_int16_planes(A, tmp_path, grid):
     channelizers (iqa_f32_split_s16: x = 2^shift (hi + lo / 32768) / 32768, z = 2^shift (z(hi) + 2^-15 z(lo))) instead
     of the float32 VALU kernel: NFM audio within 2e-5 RMS of the oracle's float32 ingest of the very same values, two
     device blocks (the low plane's channelizers carry their own history)."""
-    fs, secs = 2.5e6, 2 * 1_048_576 / 2.5e6 + 0.11
+    fs, secs = 2.5e6, 2.9 * 1_048_576 / 2.5e6  # (the last block long enough for the matrix-core kernels: 36 k outputs)
     s16 = O.synth_capture_s16(FS, secs, F_OFF).reshape(-1)
     if grid == "rtlsdr":
         u8 = np.clip((s16.astype(np.int32) >> 8) + 128, 0, 255).astype(np.uint8)
