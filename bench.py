@@ -247,7 +247,7 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
     del r_fast
     torch.cuda.empty_cache()
     dt, chan_ms, tk, res, runner = timed(C3_TARGETS)
-    launch = tk["launch"]
+    launch = getattr(runner, "last_bank_launches", None) or [tk["launch"]]  # (one entry per shared-ingest launch of a capture)
     # parity per target on the un-tiled prefix (whole reference chunks are not needed: the oracle sees the same frames)
     n_cpu = int(round(cpu_seconds_of_signal * fs))
     parity = []
@@ -277,11 +277,11 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
         "value": round(n / dt / 1e6, 1), "unit": "MS/s of capture", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
         "channel_samples_per_s": round(len(C3_TARGETS) * n / dt / 1e9, 2),
         "replays_redone": dict(runner.redone),
-        "roofline": {"bound": "mfma", "kernel": "k_channelize_mfma_s16_ring" + ("_pairs" if launch and launch.get("pairs") else "_multi")
-                                               + " (shared pass) + k_channelize_mfma_s16 (the 'full'-precision targets' chained passes)",
+        "roofline": {"bound": "mfma", "kernel": "k_channelize_mfma_s16_ring" + ("_pairs" if any(l_ and l_.get("pairs") for l_ in launch) else "_multi")
+                                               + " (int32 sums: the 'fast' targets) + the same with 64-bit sums (the 'full' targets: taps + residue lanes)",
                      "launch": launch, "kernel_ms": round(chan_ms, 4),
                      "note": "kernel_ms = every channelizer launch of a capture on the caller's stream, by events: the shared multi-lane "
-                             "pass of the 'fast' targets and the chained per-lane passes of the 'full' ones (the combine launches run on "
+                             "pass of the 'fast' targets and the one of the 'full' targets (the combine launches run on "
                              "the side stream and are not in it); achieved = algorithmic int8 ops (3 int8 MACs per 16x16-bit tap x sample "
                              "MAC) / kernel time; peak = dense int8 MFMA (2 x the 2.5 PFLOP/s bf16 figure of MI355X_MICROARCH.md)",
                      "achieved": round(int8_ops / (chan_ms * 1e-3) / 1e12, 1), "peak": 5000.0, "unit": "TOP/s",

@@ -196,7 +196,9 @@ typedef struct {
     int32_t q_group, finalize, conj_sum, rotate;
     int32_t raw_partials;       /* finalize == 0 and no partial_in: partial_out_dev is int32[2*n_out], the integer sums
                                  * (256*S1 + S2 per component) themselves; iqa_mfma_combine scales them (raw_scale) */
-    int32_t reserved;
+    int32_t reserved;           /* bit 0: 64-bit sums ((S1 << 32) + S2 per component: fragments WITHOUT the int32 bound, 16-bit
+                                 * taps -- dsp_plan.plan_mfma(acc32=False)); the same for every lane of a launch; contiguous
+                                 * slots only, no raw_partials.  See iqa_mfma_ring_lanes. */
 } iqa_mfma_lane;
 int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
                               int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,
@@ -217,6 +219,12 @@ int iqa_channelize_mfma_pairs(int32_t fmt, int32_t decimation, int32_t k_first, 
                               const void *raw_dev, int64_t n_frames, int64_t consumed, int64_t m_first,
                               int64_t n_out, void *stream);
 int32_t iqa_mfma_ring_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count);
+/* What the multi-lane launches offer for a pass over k steps [k_first, k_first + k_count) at this decimation and sum
+ * width (acc32 != 0: one int32 per component; 0: one int64, iqa_mfma_lane.reserved bit 0): bit 0 = iqa_channelize_mfma_multi,
+ * bit 1 = iqa_channelize_mfma_pairs.  0: no shared-ingest launch (64-bit sums need contiguous slots: D % 4 == 0, D <= 240;
+ * their pairs 9..14 k steps).  The "full" precision of the host pipeline puts a filter's tap-row groups AND the residue of
+ * their quantisation into such a launch as lanes (ref: the per---ft loop of the reference CLI, cli.py:683-710). */
+int32_t iqa_mfma_ring_lanes(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32);
 /* z[m_first + i] = finish(sum_k partials_dev[k][i]): the float32 conversion, conjugation, rotation and scaling of the
  * kernels' own emission (p supplies conj_sum, rotate, rot_step, rot_base, out_scale).  1..16 buffers of double2[n_out]
  * (a filter's tap-row groups -- and, with residual quantisation, each group's second lane: dsp_plan.plan_mfma(residual=True)),

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "iqa_channelize_mfma_pairs": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, ctypes.POINTER(MfmaLane), c_int32,
                                                  c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "iqa_mfma_ring_pairs": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "iqa_mfma_ring_lanes": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "iqa_mfma_combine": (ctypes.c_int, [ctypes.POINTER(ChanParams), ctypes.POINTER(c_void_p), c_int32, ctypes.POINTER(c_double),
                                         c_int64, c_int64, c_void_p, c_void_p]),
     "iqa_history_update": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

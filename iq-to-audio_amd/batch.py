@@ -535,6 +535,7 @@ class ResidentBankRunner:
         bank.process(raw_dev, outs=[p["z"] for p in slot["per"]], last_block=True, halo=halo, edge_stream=side)
         if events:
             events[1].record()
+        self.last_bank_launches = getattr(bank, "launches", None) or [bank.last_launch]  # (one entry per shared launch of the capture)
         # The targets' demodulator / resampler / copy chains run on ONE side stream behind the channelizer pass (and behind
         # this capture's probes and float32 edge launches, queued there above), so the next capture's channelizer pass
         # (other slot, caller's stream) does not wait for them.  The pass is

@@ -373,10 +373,15 @@ static int channelize_mfma_lanes(int32_t fmt, int32_t decimation, int32_t k_firs
     if (k_first < 0 || ksteps <= 0 || k_first + ksteps > ksteps_all) return fail_inval("bad k-step range");
     const int range = outputs_per_block;
     if (range <= 0 || (range & 31)) return fail_inval("outputs_per_block must be a positive multiple of 32");
-    const int ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, false, u8);
-    if (ring_mode == 0) return fail_inval("the ring kernel does not cover this (decimation, k-step range): see iqa_mfma_ring_mode");
-    if (pairs && !mfma_ring_pairs_supported(static_cast<int>(D), k_first, ksteps, u8))
-        return fail_inval("lane pairs are not available for this (format, decimation, k-step range): see iqa_mfma_ring_pairs");
+    // 64-bit sums (iqa_mfma_lane.reserved bit 0, the same for every lane of a launch): fragments without the int32 bound
+    const bool acc64 = (lanes[0].reserved & 1) != 0;
+    for (int i = 1; i < n_lanes; ++i)
+        if (lanes[i].afrag_dev && ((lanes[i].reserved & 1) != 0) != acc64) return fail_inval("the lanes of a launch share the sum width (reserved bit 0)");
+    const int ring_mode = mfma_ring_mode(static_cast<int>(D), k_first, ksteps, acc64, u8);
+    if (ring_mode == 0) return fail_inval("the ring kernel does not cover this (decimation, k-step range, sum width): see iqa_mfma_ring_mode");
+    if (acc64 && ring_mode != 1) return fail_inval("64-bit sums: contiguous slots only");
+    if (pairs && !mfma_ring_pairs_supported(static_cast<int>(D), k_first, ksteps, u8, acc64))
+        return fail_inval("lane pairs are not available for this (format, decimation, k-step range, sum width): see iqa_mfma_ring_lanes");
     // every frame any lane touches must lie inside [0, n_frames): the lane with the largest tap-row group reads the
     // earliest data rows, group 0 the latest (see iqa_channelize_mfma for the geometry)
     int q_max = 0;
@@ -411,7 +416,7 @@ static int channelize_mfma_lanes(int32_t fmt, int32_t decimation, int32_t k_firs
     a.ksteps = ksteps;
     a.range = range;
     a.k_first = k_first;
-    a.debug = 64 | 128;
+    a.debug = 64 | (acc64 ? 0 : 128);
     MfmaLane packed[16];
     if (n_lanes > 16) return fail_inval("at most 16 lanes per launch");
     for (int i = 0; i < n_lanes; ++i) {
@@ -438,8 +443,9 @@ static int channelize_mfma_lanes(int32_t fmt, int32_t decimation, int32_t k_firs
         l.rotate = s.rotate;
         l.raw_partials = (s.raw_partials != 0 && !s.finalize && !s.partial_in_dev) ? 1 : 0;
         if (s.raw_partials && !l.raw_partials) return fail_inval("raw partials need finalize == 0 and no partial_in");
+        if (s.raw_partials && acc64) return fail_inval("raw partials are int32 sums: not with 64-bit sums");
     }
-    return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr, pairs);
+    return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr, pairs, acc64);
 }
 
 extern "C" int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
@@ -458,6 +464,17 @@ extern "C" int iqa_channelize_mfma_pairs(int32_t fmt, int32_t decimation, int32_
 {
     return channelize_mfma_lanes(fmt, decimation, k_first, k_count, outputs_per_block, lanes, n_lanes, raw_dev, n_frames, consumed,
                                  m_first, n_out, stream, true);
+}
+
+extern "C" int32_t iqa_mfma_ring_lanes(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count, int32_t acc32)
+{
+    if (decimation < 1 || (fmt != IQA_FMT_S16 && fmt != IQA_FMT_U8)) return 0;
+    const bool u8 = fmt == IQA_FMT_U8, acc64 = acc32 == 0;
+    const int ks_all = (2 * decimation + 31) / 32;
+    const int ks = k_count > 0 ? k_count : ks_all - k_first;
+    const int mode = mfma_ring_mode(decimation, k_first, ks, acc64, u8);
+    if (mode == 0 || (acc64 && mode != 1)) return 0;
+    return 1 | (mfma_ring_pairs_supported(decimation, k_first, ks, u8, acc64) ? 2 : 0);
 }
 
 extern "C" int32_t iqa_mfma_ring_pairs(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count)

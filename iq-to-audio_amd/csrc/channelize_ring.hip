@@ -779,7 +779,7 @@ struct RingMultiArgs {
     RingLane lane[RG_MAX_LANES];
 };
 
-template <int KS, bool ROWS, bool U8, bool PAIR = false>
+template <int KS, bool ROWS, bool U8, bool PAIR = false, bool ACC64 = false>
 __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
 {
     const int idx = blockIdx.x >> 3;
@@ -824,20 +824,22 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
         a.pace_slot = static_cast<int>(range_idx) * units + idx % units;
     }
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
-    ring_block<KS, 0, false, ROWS, U8, PAIR>(a, range_idx);
+    ring_block<KS, 0, ACC64, ROWS, U8, PAIR>(a, range_idx);
 }
 
-template <int KS>
+// ACC64: one int64 (S1 << 32) + S2 per output component instead of one int32 256*S1 + S2 -- 16-bit taps without the int32
+// bound, what the "full" precision's lanes (taps + their residue, dsp_plan.plan_mfma(residual=True)) need; contiguous slots only.
+template <int KS, bool ACC64 = false>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_multi(RingMultiArgs m)
 {
-    ring_multi_block<KS, false, false>(m);
+    ring_multi_block<KS, false, false, false, ACC64>(m);
 }
 
 // Two lanes per workgroup (RingGeo PAIR): the lanes of the table in pairs of equal tap-row group.
-template <int KS>
+template <int KS, bool ACC64 = false>
 __global__ __launch_bounds__((RingGeo<KS, false, false, true>::THREADS), 2) void k_channelize_mfma_s16_ring_pairs(RingMultiArgs m)
 {
-    ring_multi_block<KS, false, false, true>(m);
+    ring_multi_block<KS, false, false, true, ACC64>(m);
 }
 
 template <int KS>
@@ -902,9 +904,17 @@ static int ring_launch_rows_u8(const MfmaArgs &a, unsigned blocks, size_t lds, h
 }
 
 template <int KS>
-static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
+static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8, bool acc64)
 {
-    static std::atomic<unsigned long long> done[3] = {{0}, {0}, {0}};
+    static std::atomic<unsigned long long> done[4] = {{0}, {0}, {0}, {0}};
+    if (acc64) {
+        if constexpr (KS < RG_MAX_KS) {  // (64-bit sums at 16 k steps do not fit the registers)
+            if (!rows && !u8)
+                return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS, true>, "k_channelize_mfma_s16_ring_multi64", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[3]);
+        }
+        set_error("multi-lane launches with 64-bit sums: contiguous int16 slots, at most %d k steps (got %d)", RG_MAX_KS - 1, KS);
+        return IQA_EINVAL;
+    }
     if constexpr (KS <= RG_ROWS_MAX_KS_C) {
         if (u8) return ring_launch_kernel(k_channelize_mfma_u8_ring_rows_multi<KS>, "k_channelize_mfma_u8_ring_rows_multi", RingGeo<KS, true, true>::THREADS, m, blocks, lds, stream, done[2]);
         if (rows) return ring_launch_kernel(k_channelize_mfma_s16_ring_rows_multi<KS>, "k_channelize_mfma_s16_ring_rows_multi", RingGeo<KS, true>::THREADS, m, blocks, lds, stream, done[1]);
@@ -920,11 +930,17 @@ static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds
 constexpr int RG_PAIR_MIN_KS = IQA_RING_LOADERS_MAX_KS + 1;  // lane pairs where the single-lane kernel runs without loader waves
 
 template <int KS>
-static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_t stream)
+static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_t stream, bool acc64)
 {
-    static std::atomic<unsigned long long> done{0};
+    static std::atomic<unsigned long long> done{0}, done64{0};
     if constexpr (KS >= RG_PAIR_MIN_KS) {
         using G = RingGeo<KS, false, false, true>;
+        if (acc64) {
+            if constexpr (KS <= 14)
+                return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS, true>, "k_channelize_mfma_s16_ring_pairs64", G::THREADS, m, blocks, G::LDS_BYTES, stream, done64);
+            set_error("lane pairs with 64-bit sums: 9..14 k steps (got %d)", KS);
+            return IQA_EINVAL;
+        }
         return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS>, "k_channelize_mfma_s16_ring_pairs", G::THREADS, m, blocks, G::LDS_BYTES, stream, done);
     } else {
         set_error("lane pairs need at least %d k steps (got %d)", RG_PAIR_MIN_KS, KS);
@@ -975,11 +991,11 @@ static unsigned int *ring_pace_buffer(unsigned int &token, int words, hipStream_
     return mine;
 }
 
-bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8)
+bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8, bool acc64)
 {
     // (15 k steps: the pair kernel would need 20 registers more than a wave has -- a spill's scratch loads would join
-    // the counted vmcnt sequence of the issuing waves)
-    return mfma_ring_mode(decimation, k_first, k_count, false, u8) == 1 && k_count >= RG_PAIR_MIN_KS && k_count != 15;
+    // the counted vmcnt sequence of the issuing waves; 64-bit sums cost ~20 registers more: up to 14 k steps)
+    return mfma_ring_mode(decimation, k_first, k_count, acc64, u8) == 1 && k_count >= RG_PAIR_MIN_KS && k_count != 15 && (!acc64 || k_count <= 14);
 }
 
 constexpr int RG_ROWS_MAX_KS = RG_ROWS_MAX_KS_C;  // 8*KS tap registers + the rest must stay within 168 (three waves on two SIMDs)
@@ -1092,7 +1108,7 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
 // Several lanes (channels x tap-row groups) of one capture in one launch; int32 sums only.  `lanes` holds n_lanes
 // entries whose fields mirror the per-lane part of MfmaArgs; `a` carries what they share.
 int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes, size_t lds, hipStream_t stream, bool rows, bool u8,
-                           unsigned *blocks_out, bool pairs)
+                           unsigned *blocks_out, bool pairs, bool acc64)
 {
     if (n_lanes < 1 || n_lanes > RG_MAX_LANES) {
         set_error("a multi-lane launch takes 1..%d lanes (got %d)", RG_MAX_LANES, n_lanes);
@@ -1143,7 +1159,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         m.c.pace = nullptr;
         m.c.pace = ring_pace_buffer(m.c.pace_token, static_cast<int>(std::min<long long>(groups * 8 * (n_lanes / 2), RG_PACE_WORDS + 1)), stream);
         switch (a.ksteps) {
-#define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream)
+#define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream, acc64)
             RG_PAIRS(9); RG_PAIRS(10); RG_PAIRS(11); RG_PAIRS(12); RG_PAIRS(13); RG_PAIRS(14); RG_PAIRS(16);
 #undef RG_PAIRS
             default: break;
@@ -1152,7 +1168,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         return IQA_EINVAL;
     }
     switch (a.ksteps) {
-#define RG_MULTI(K) case K: return ring_launch_multi<K>(m, blocks, lds, stream, rows, u8)
+#define RG_MULTI(K) case K: return ring_launch_multi<K>(m, blocks, lds, stream, rows, u8, acc64)
         RG_MULTI(1); RG_MULTI(2); RG_MULTI(3); RG_MULTI(4); RG_MULTI(5); RG_MULTI(6); RG_MULTI(7); RG_MULTI(8);
         RG_MULTI(9); RG_MULTI(10); RG_MULTI(11); RG_MULTI(12); RG_MULTI(13); RG_MULTI(14); RG_MULTI(15); RG_MULTI(16);
 #undef RG_MULTI

@@ -121,7 +121,7 @@ struct MfmaLane {
     int col_shift, finalize, conj_sum, rotate, raw_partials;
 };
 int mfma_ring_launch_multi(const MfmaArgs &common, const MfmaLane *lanes, int n_lanes, size_t lds_bytes, hipStream_t stream, bool rows,
-                           bool u8, unsigned *blocks_out, bool pairs = false);
-bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8);  // two lanes per workgroup (contiguous slots, no loader waves)
+                           bool u8, unsigned *blocks_out, bool pairs = false, bool acc64 = false);
+bool mfma_ring_pairs_supported(int decimation, int k_first, int k_count, bool u8, bool acc64 = false);  // two lanes per workgroup (contiguous slots, no loader waves)
 
 }  // namespace iqa

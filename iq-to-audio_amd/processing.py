@@ -167,9 +167,11 @@ class _ChannelKernel:
     #:   "fast"    -- the ring kernels, ONE int32 sum per output component, ~14-bit taps: z error ~3e-6 of full scale
     #:   "fine"    -- the same kernels, every tap-row group as TWO lanes (high-byte-only taps + their residue, added by
     #:                iqa_mfma_combine): twice the matrix work, error 10..90x smaller; uint8 captures: exact products
-    #:   "full"    -- the per-lane kernel (separate S1/S2 sums, no int32 bound: 16-bit taps) with the same two groups as
-    #:                chained passes: z error ~1e-9 of full scale -- below the float32 rounding of z itself -- at ~2.5x the
-    #:                time of "fast" (int16 captures; uint8 -> "fine", float32 -> "float32")
+    #:   "full"    -- 16-bit taps without the int32 bound, the same two groups: z error ~1e-9 of full scale -- below the float32
+    #:                rounding of z itself -- at ~2.3x the time of "fast".  Contiguous ring slots (D % 4 == 0, <= 15 k steps):
+    #:                lanes of the ring kernels with 64-bit sums (shared ingest, pairs at 9..14 k steps); every other
+    #:                decimation: chained passes of the per-lane kernel (separate S1/S2 sums).  int16 captures; uint8 ->
+    #:                "fine", float32 -> "float32"
     #:   "float32" -- the float32 VALU kernel for every output (~20x the time of "fast"; the only form for float32 captures)
     PRECISIONS = ("fast", "fine", "full", "float32")
 
@@ -184,7 +186,7 @@ class _ChannelKernel:
             precision = "fine"
         self.precision = precision
         self.exact = precision == "float32"  # float32 kernel everywhere
-        self.variant = "plain" if precision == "full" else self.mfma_variant
+        self.variant = self.mfma_variant  # ("full" off the contiguous ring slots: no ring mode below -> the per-lane kernel)
         self.acc32 = bool(self.ring_acc32) and precision != "full"
         self.residual = precision in ("fine", "full")
         lpad = int(N.lib().iqa_taps_padded_len(plan.ntaps))
@@ -575,7 +577,7 @@ class Channelizer:
 
     def _several_lanes(self) -> bool:
         k = self._kernel
-        if not (self.lanes_for_groups and self.fmt in ("s16", "u8") and k._mfma_ok and k.variant == "ring" and k._ring_mode and k.acc32):
+        if not (self.lanes_for_groups and self.fmt in ("s16", "u8") and ChannelBank._lane_capable(k)):
             return False
         return len(k._ensure_mfma().groups) > 1
 
@@ -622,12 +624,13 @@ class ChannelBank:
 
     @staticmethod
     def _lane_capable(k) -> bool:
-        """This channel's tap-row groups can be lanes of a shared-ingest launch (ring kernels, int32 sums)."""
-        return bool(k._mfma_ok and k.variant == "ring" and k._ring_mode and k.acc32)
+        """This channel's tap-row groups can be lanes of a shared-ingest launch: ring kernels with int32 sums (any slot
+        form) or with 64-bit sums (contiguous slots only)."""
+        return bool(k._mfma_ok and k.variant == "ring" and k._ring_mode and (k.acc32 or k._ring_mode == 1))
 
     def _shared_shape(self) -> bool:
         ks = [c._kernel for c in self.chans]
-        if not ks or not all(self._lane_capable(k) for k in ks):
+        if not ks or not all(self._lane_capable(k) for k in ks) or len({k.acc32 for k in ks}) != 1:
             return False
         if len(ks) == 1:  # one channel: worth a shared-ingest launch only when its filter is several lanes (tap-row groups)
             return len(ks[0]._ensure_mfma().groups) > 1
@@ -647,16 +650,23 @@ class ChannelBank:
             zs = self._run_shared(x, n, m_first, n_out, outs, halo, edge_stream)
         if zs is None:
             self.last_launch = None
-            lanes = [i for i, c in enumerate(self.chans) if self._lane_capable(c._kernel)]
-            if 0 < len(lanes) < len(self.chans) and D.is_tensor(raw):
-                # channels of other precisions ("full": chained passes of the per-lane kernel; "float32") in the bank: the
-                # lane-capable ones still share their pass, the others follow one by one
-                sub = ChannelBank([self.chans[i] for i in lanes])
-                got = sub.process(raw, outs=[outs[i] for i in lanes], last_block=last_block, halo=halo, edge_stream=edge_stream)
-                self.last_launch = sub.last_launch
+            capable = [i for i, c in enumerate(self.chans) if self._lane_capable(c._kernel)]
+            widths = sorted({self.chans[i]._kernel.acc32 for i in capable}, reverse=True)
+            if D.is_tensor(raw) and capable and (len(capable) < len(self.chans) or len(widths) > 1):
+                # channels of several precisions in the bank: the lanes with int32 sums share one pass, the lanes with
+                # 64-bit sums ("full") another, whatever has no lanes ("full" off the contiguous slots, "float32") follows
+                # one by one
                 res = [None] * len(self.chans)
-                for i, z in zip(lanes, got):
-                    res[i] = z
+                self.last_launch, self.launches = None, []
+                for acc32 in widths:
+                    lanes = [i for i in capable if self.chans[i]._kernel.acc32 == acc32]
+                    sub = ChannelBank([self.chans[i] for i in lanes])
+                    got = sub.process(raw, outs=[outs[i] for i in lanes], last_block=last_block, halo=halo, edge_stream=edge_stream)
+                    self.launches.append(sub.last_launch)
+                    if self.last_launch is None:
+                        self.last_launch = sub.last_launch
+                    for i, z in zip(lanes, got):
+                        res[i] = z
                 for i, (c, o) in enumerate(zip(self.chans, outs)):
                     if res[i] is None:
                         res[i] = c.process(raw, out_dev=o, last_block=last_block, halo=halo)
@@ -734,8 +744,9 @@ class ChannelBank:
         ids = [(ci, gi) for ci, mp in enumerate(plans) for gi in range(len(mp.groups))]  # lane identities
         need_partial = {(ci, gi): (len(kranges) > 1 or len(plans[ci].groups) > 1) for ci, gi in ids}
         # single k-step range: a tap-row group's partial sums travel as the exact int32 pairs (8 B per output) and the
-        # combine kernel scales them; chained k-step ranges hand double2 sums from pass to pass (16 B)
-        raw = len(kranges) == 1
+        # combine kernel scales them; chained k-step ranges -- and lanes with 64-bit sums -- hand on double2 sums (16 B)
+        acc32 = bool(kernels[0].acc32)
+        raw = len(kranges) == 1 and acc32
         partial = {key: D.empty(2 * n_int, "int32" if raw else "float64") for key, needed in need_partial.items() if needed}
         cpx = max(1, _ChannelKernel.launch_blocks // 8)  # CUs per XCD class the launch may fill
         launches = 0
@@ -767,6 +778,7 @@ class ChannelBank:
                     lane.q_group, lane.finalize = mp.groups[gi].q, int(fin)
                     lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
                     lane.raw_partials = int(raw and not fin)
+                    lane.reserved = 0 if acc32 else 1  # (bit 0: 64-bit sums)
                 N.call(entry, c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first), c_int32(k_count), c_int32(rng),
                        table, c_int32(len(part)), N.ptr(big), c_int64(big_frames), c_int64(big_consumed), c_int64(m_a), c_int64(n_int),
                        N.stream_ptr())
@@ -777,7 +789,7 @@ class ChannelBank:
         # rounds.  A pair's first lane has the larger (or the same) tap-row group: lanes in descending group order, two
         # by two; an odd lane out shares its workgroup with nobody (None).  ONE launch either way: the capture crosses
         # HBM once.
-        if self.pair_lanes and len(kranges) == 1 and N.lib().iqa_mfma_ring_pairs(P.FMT_CODE[self.fmt], self.decimation, *kranges[0]):
+        if self.pair_lanes and len(kranges) == 1 and (N.lib().iqa_mfma_ring_lanes(P.FMT_CODE[self.fmt], self.decimation, *kranges[0], int(acc32)) & 2):
             paired = sorted(ids, key=lambda i: -plans[i[0]].groups[i[1]].q)
             if len(paired) & 1:
                 paired.append(None)

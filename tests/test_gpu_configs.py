@@ -241,10 +241,11 @@ def test_config3_workload_five_mixed_targets_agc_on(A, tmp_path):
     finally:
         PR._ChannelKernel.mfma_min_outputs = old_min
     assert len(results) == 5
-    # NFM / AM: lanes of the shared ring launch ("fast"); USB / LSB with the AGC on: "full" precision, chained passes of the per-lane kernel
+    # NFM / AM: lanes of the shared ring launch with int32 sums ("fast"); USB / LSB with the AGC on: "full" precision -- every
+    # tap-row group and the residue of its quantisation as lanes of a SECOND shared launch, with 64-bit sums (lane pairs)
     assert [o.channelizer_precision for o in multi.owners] == ["fast", "fast", "full", "full", "fast"]
-    assert [o.channelizer_kernel for o in multi.owners] == ["k_channelize_mfma_s16_ring"] * 2 + ["k_channelize_mfma_s16"] * 2 + ["k_channelize_mfma_s16_ring"]
-    assert multi.banks[0].last_launch["lanes"] == 1 + 2 + 1  # the three "fast" targets still share ONE pass
+    assert all(o.channelizer_kernel == "k_channelize_mfma_s16_ring" for o in multi.owners)
+    assert multi.banks[0].launches == [dict(lanes=1 + 2 + 1, launches=1, combines=1, pairs=2), dict(lanes=2 * (3 + 3), launches=1, combines=2, pairs=6)]
     chunk = 4_194_304
     for i, (((off, _, _), (mode, bw)), res, owner) in enumerate(zip(C3_TARGETS, results, multi.owners)):
         want = O.run_chain(raw, sample_rate=fs, freq_offset=off, bandwidth=bw, demod_mode=mode, agc_enabled=True)
@@ -671,7 +672,8 @@ def test_channelizer_precision_ladder_against_the_oracle(A):
                 print(f"precision ladder | {label:32s} | {prec:8s} {ch._kernel.last_kernel:28s}: z rms err {err:.2e} (predicted {pred:.2e})")
             e = {p_: rows[(label, p_)][0] for p_ in PR._ChannelKernel.PRECISIONS}
             assert rows[(label, "fast")][2].endswith("_ring") and rows[(label, "fine")][2].endswith("_ring")
-            assert rows[(label, "full")][2] == "k_channelize_mfma_s16" and rows[(label, "float32")][2] == "k_channelize_v1"
+            # ("full" on contiguous ring slots: lanes with 64-bit sums; the per-lane kernel only where those do not apply)
+            assert rows[(label, "full")][2] == "k_channelize_mfma_s16_ring" and rows[(label, "float32")][2] == "k_channelize_v1"
             assert e["fast"] < 4e-5 and e["fine"] * 5.0 < e["fast"] and e["full"] * 5.0 < e["fine"], e
             assert e["full"] < 3e-8 and e["float32"] < 3e-7, e  # (z itself is float32: ~1e-8 of rounding on either side)
             for p_ in ("fast", "fine"):
