@@ -266,7 +266,7 @@ int iqa_mean_power(const void *z_dev, int64_t n, int64_t skip, void *power_dev, 
 int iqa_mean_power_batch(const void *z_dev, int64_t n_each, int32_t parts, int64_t skip, void *power_dev, void *stream);
 
 /* Wideband level of raw capture frames: *mean_square_out (double[1], WRITTEN by one workgroup: device or mapped pinned
- * host memory) = mean of value^2 over up to 65536 values sampled evenly from raw_dev[0 : n_values] (int16 / uint8 - 128 /
+ * host memory) = mean of value^2 over up to 65536 values -- eight 16 KiB stretches spread evenly over raw_dev[0 : n_values] (int16 / uint8 - 128 /
  * float32 values, I and Q alike; raw_dev 16-byte aligned).  The caller scales: wideband RMS of the complex samples =
  * sqrt(2 * mean_square) * ingest scale.  It is the reference level of the precision guard of the fixed-point
  * channelizers (a channel far below the wideband level is re-run at a finer precision); the reference needs none -- its

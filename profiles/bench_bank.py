@@ -35,8 +35,14 @@ raw = buf[: 2 * n_total]
 n_dec = -(-n_total // d)
 outs = [D.empty(n_dec, "complex64") for _ in targets]
 
+PREC = os.environ.get("PREC", "fast")  # "fast": every target at the default precision (round 2's workload); "product": what the
+                                       # pipeline picks per demodulator (USB / LSB with the AGC on at "full": processing.base_precision)
+
+
 def make():
-    return [A.Channelizer(A.design_channel_filter(fs, bw, d), sample_rate=fs, freq_offset=off, mix_sign=1, decimation=d) for off, _, bw in targets]
+    from iq_to_audio_amd.processing import base_precision
+    return [A.Channelizer(A.design_channel_filter(fs, bw, d), sample_rate=fs, freq_offset=off, mix_sign=1, decimation=d,
+                          precision=base_precision(mode, True) if PREC == "product" else "fast") for off, mode, bw in targets]
 
 def run(mode):
     chans = make()

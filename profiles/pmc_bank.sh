@@ -32,7 +32,7 @@ for p in ("fetch", "write", "p1", "p2", "p3"):
         print(p, "no counters; tail of log:"); print(open(f"{out}/{p}.log").read()[-600:]); continue
     agg = defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "ring" in r["Kernel_Name"] and "multi" in r["Kernel_Name"]:
+        if "ring" in r["Kernel_Name"] and ("multi" in r["Kernel_Name"] or "pairs" in r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         med = sorted(v)[len(v) // 2]

@@ -35,7 +35,7 @@ def med(v):
     return sorted(v)[len(v) // 2]
 
 
-summary = {"tag": tag, "command": "python profiles/bench_bank.py c3 bank (K=6, WARM=2)",
+summary = {"tag": tag, "command": f"PREC={os.environ.get('PREC', 'fast')} python profiles/bench_bank.py c3 bank (K=6, WARM=2)",
            "workload": "BASELINE config 3: 60 s @ 20 MS/s = 1.2e9 frames, five targets nfm/am/usb/lsb/nfm = 10 lanes, D = 208"}
 stats = newest("stats", "*kernel_stats.csv")
 if stats:
@@ -56,35 +56,45 @@ for k in set(fetch) | set(write):
     traffic[k] = {"launches_profiled": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KiB_median": f, "WRITE_SIZE_KiB_median": w,
                   "read_bytes_per_launch": (2.0 if wide else 1.0) * f * 1024.0, "written_bytes_per_launch": w * 1024.0}
 summary["hbm_traffic"] = traffic
-ring = next((v for k, v in traffic.items() if "ring_multi" in k or "ring_pairs" in k), None)
-comb = next((v for k, v in traffic.items() if "combine" in k), None)
 n, targets = 1.2e9, 5
 algo = 4.0 * n + targets * 4.0 * 48000.0 / 20e6 * n
-if ring:
-    per_capture = ring["read_bytes_per_launch"] + ring["written_bytes_per_launch"]
+# bytes per CAPTURE: every launch of every channelizer kernel (the shared launches with int32 and with 64-bit sums, the
+# combine launches) over all profiled captures, divided by their number (K + WARM of profiles/pmc_bank.sh)
+captures = float(os.environ.get("CAPTURES", "8"))
+prec = os.environ.get("PREC", "fast")
+summary["workload_key"] = "c3_product_precisions" if prec == "product" else "c3_all_fast"
+summary["precisions"] = prec
+ring_bytes = comb_bytes = 0.0
+for k in traffic:
+    tot = ((2.0 if "ring" in k else 1.0) * sum(fetch[k]["FETCH_SIZE"]) + sum(write[k]["WRITE_SIZE"])) * 1024.0 / captures
+    traffic[k]["bytes_per_capture"] = tot
+    if "combine" in k:
+        comb_bytes += tot
+    elif "channelize" in k:
+        ring_bytes += tot
+if ring_bytes:
     summary["algorithmic_bytes_per_capture"] = algo
-    summary["multi_lane_kernel_bytes_per_capture"] = per_capture
-    summary["multi_lane_kernel_traffic_over_algorithmic"] = per_capture / algo
-    if comb:
-        # three combine launches per capture (am: 2 groups, usb / lsb: 3 groups each): the profiled launches hold them in turn
-        k = next(k for k in traffic if "combine" in k)
-        per_capture_comb = (sum(fetch[k]["FETCH_SIZE"]) + sum(write[k]["WRITE_SIZE"])) * 1024.0 / (len(fetch[k]["FETCH_SIZE"]) / 3.0)
-        summary["combine_kernels_bytes_per_capture"] = per_capture_comb
-        summary["channelizer_stage_traffic_over_algorithmic"] = (per_capture + per_capture_comb) / algo
+    summary["multi_lane_kernel_bytes_per_capture"] = ring_bytes
+    summary["multi_lane_kernel_traffic_over_algorithmic"] = ring_bytes / algo
+    summary["combine_kernels_bytes_per_capture"] = comb_bytes
+    summary["channelizer_stage_traffic_over_algorithmic"] = (ring_bytes + comb_bytes) / algo
+by_kernel = defaultdict(dict)
 for p in ("p1", "p2", "p3"):
     c = counters(p)
     for k, v in c.items():
         if "ring_multi" in k or "ring_pairs" in k:
-            summary.setdefault("ring_multi_counters_median", {}).update({name: med(vals) for name, vals in v.items()})
-cm = summary.get("ring_multi_counters_median", {})
-if cm.get("GRBM_GUI_ACTIVE") and summary.get("kernel_stats"):
-    ms = next(v["avg_ms"] for k, v in summary["kernel_stats"].items() if "ring_multi" in k or "ring_pairs" in k)
+            by_kernel[k].update({name: med(vals) for name, vals in v.items()})
+summary["ring_counters_median_by_kernel"] = by_kernel
+summary["derived"] = {}
+for k, cm in by_kernel.items():
+    if not cm.get("GRBM_GUI_ACTIVE"):
+        continue
     cyc = cm["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-    summary["derived"] = {"kernel_cycles": cyc, "note": "GRBM_GUI_ACTIVE / 8; clock = cycles / the profiled pass's own duration (not kept): ~1.9 GHz",
-                          "mfma_busy_of_all_simd_cycles": cm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024.0),
-                          "mfma_busy_of_the_240_working_cus": cm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 960.0),
-                          "lds_array_busy_per_working_cu": cm.get("SQ_LDS_IDX_ACTIVE", 0) / 240.0 / cyc,
-                          "lds_bank_conflict_cycles": cm.get("SQ_LDS_BANK_CONFLICT"),
-                          "l2_hit_rate": cm.get("TCC_HIT_sum", 0) / max(1.0, cm.get("TCC_HIT_sum", 0) + cm.get("TCC_MISS_sum", 0))}
+    summary["derived"][k] = {"kernel_cycles": cyc, "note": "GRBM_GUI_ACTIVE / 8",
+                             "mfma_busy_of_all_simd_cycles": cm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024.0),
+                             "mfma_busy_of_the_240_working_cus": cm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 960.0),
+                             "lds_array_busy_per_working_cu": cm.get("SQ_LDS_IDX_ACTIVE", 0) / 240.0 / cyc,
+                             "lds_bank_conflict_cycles": cm.get("SQ_LDS_BANK_CONFLICT"),
+                             "l2_hit_rate": cm.get("TCC_HIT_sum", 0) / max(1.0, cm.get("TCC_HIT_sum", 0) + cm.get("TCC_MISS_sum", 0))}
 (dest / f"{tag}_bank_pmc_summary.json").write_text(json.dumps(summary, indent=1) + "\n")
 print(json.dumps(summary, indent=1))
