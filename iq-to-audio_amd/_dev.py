@@ -81,6 +81,12 @@ _pin_pool: dict[int, list] = {}
 def _upload(torch, arr: np.ndarray):
     nbytes = arr.nbytes
     if nbytes > _PIN_LIMIT:
+        if not arr.flags.writeable:  # (shared read-only plans: torch warns about tensors over read-only memory; this one is only copied from)
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return torch.from_numpy(arr).to(device())
         return torch.from_numpy(arr).to(device())
     cls = max(256, 1 << (nbytes - 1).bit_length())
     slots = _pin_pool.setdefault(cls, [])
@@ -99,7 +105,7 @@ def _upload(torch, arr: np.ndarray):
     ev = torch.cuda.Event()
     ev.record()
     slot[1] = ev
-    return dev.view(torch.from_numpy(arr[:0]).dtype).reshape(arr.shape)
+    return dev.view(getattr(torch, arr.dtype.name)).reshape(arr.shape)
 
 
 def like_input(result, template):

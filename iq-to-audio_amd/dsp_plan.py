@@ -407,14 +407,21 @@ class ResamplerPlan:
 
 
 def plan_resampler(fs_channel: float, out_rate: int = RS_OUT_RATE) -> ResamplerPlan:
-    """Polyphase table of the zero-phase Kaiser-sinc prototype.
+    """Polyphase table of the zero-phase Kaiser-sinc prototype (planned once per declared input rate: the table of
+    the 96 154 -> 48 000 Hz case has 1.6 M entries and its Bessel window costs ~55 ms of host NumPy -- most of a file ->
+    WAV run on the reference's own 5 s benchmark capture before it was cached).  The plan and its table are shared: do
+    not modify them.
 
     The declared input rate is round(fs_channel), exactly what the reference tells ffmpeg
     (processing.py:389-397).  Prototype (common rate up*in_rate): h[i] = sinc(0.97*i/M) *
     kaiser(beta=9) over |i| <= 16*M, M = max(up, down), scaled to sum(h) = up.
     Row p of the table holds h[p + t*up] for t = -T..T (zero outside the support).
     """
-    rin = max(1, int(round(fs_channel)))
+    return _plan_resampler(max(1, int(round(fs_channel))), int(out_rate))
+
+
+@functools.lru_cache(maxsize=16)
+def _plan_resampler(rin: int, out_rate: int) -> ResamplerPlan:
     g = math.gcd(out_rate, rin)
     up, down = out_rate // g, rin // g
     m = max(up, down)
@@ -427,5 +434,6 @@ def plan_resampler(fs_channel: float, out_rate: int = RS_OUT_RATE) -> ResamplerP
     t_half = -(-half // up)
     idx = np.arange(up, dtype=np.int64)[:, None] + np.arange(-t_half, t_half + 1, dtype=np.int64)[None, :] * up
     ok = np.abs(idx) <= half
-    table = np.where(ok, h[np.clip(idx + half, 0, 2 * half)], 0.0)
-    return ResamplerPlan(rin, up, down, int(t_half), np.ascontiguousarray(table, dtype=np.float64))
+    table = np.ascontiguousarray(np.where(ok, h[np.clip(idx + half, 0, 2 * half)], 0.0), dtype=np.float64)
+    table.setflags(write=False)
+    return ResamplerPlan(rin, up, down, int(t_half), table)

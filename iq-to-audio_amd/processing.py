@@ -1279,9 +1279,20 @@ class Resampler48k:
     """The ``-ar 48000 -acodec pcm_s16le`` leg (reference processing.py:399-418) on the GPU.
     Build-defined specification (dsp_plan.plan_resampler); parity with libswresample is unpinned."""
 
+    _TABLES: dict = {}  # (device, declared input rate) -> the polyphase table on that device (read-only, 12.9 MB at 96 154 Hz)
+
     def __init__(self, fs_channel: float):
         self.plan = P.plan_resampler(fs_channel)
-        self.table_dev = D.from_numpy(self.plan.table.reshape(-1))
+        key = (D.torch_mod().cuda.current_device(), self.plan.in_rate)
+        with _KERNEL_CACHE_LOCK:
+            table = self._TABLES.get(key)
+        if table is None:
+            table = D.from_numpy(self.plan.table.reshape(-1))
+            with _KERNEL_CACHE_LOCK:
+                if len(self._TABLES) >= 16:
+                    self._TABLES.clear()
+                self._TABLES[key] = table
+        self.table_dev = table
 
     def process(self, audio_dev, *, want: str = "f32"):
         """48 kHz audio of a whole stream: float32 (``want="f32"``), PCM16 (``"pcm16"``: what the WAV holds, rounded
@@ -1318,14 +1329,49 @@ class _BlockStager:
     Replaces the reference's ffmpeg decode pipe + ``IQReader.read_block`` (processing.py:238-266): the
     capture's own sample format goes to the GPU untouched."""
 
+    #: pinned staging buffers that finished runs gave back, by (dtype, elements): pinning 50 MB costs ~15 ms and a run
+    #: on a small capture (the reference's --benchmark: 50 MB) spent a third of its wall time on it
+    _POOL: dict = {}
+    _POOL_MAX_BYTES = 2 << 30
+    _POOL_LOCK = threading.Lock()
+
     def __init__(self, frames: np.ndarray, dtype: str, max_frames: int):
         torch = D.torch_mod()
         self.frames = frames
         self.dtype = getattr(torch, dtype)
-        self.bufs = [torch.empty(2 * max_frames, dtype=self.dtype).pin_memory() for _ in range(2)]
+        self.numel = 2 * max_frames
+        self.bufs = [None, None]  # pinned lazily: a capture of one block needs one
         self.events = [None, None]
         self.pending = None  # (thread, slot, lo, hi)
         self.slot = 0
+
+    def _buf(self, slot: int):
+        if self.bufs[slot] is None:
+            torch = D.torch_mod()
+            key = (str(self.dtype), self.numel)
+            with self._POOL_LOCK:
+                stack = self._POOL.get(key)
+                self.bufs[slot] = stack.pop() if stack else None
+            if self.bufs[slot] is None:
+                self.bufs[slot] = torch.empty(self.numel, dtype=self.dtype, pin_memory=True)
+        return self.bufs[slot]
+
+    def close(self) -> None:
+        """Give the pinned buffers back (every H2D copy out of them has completed)."""
+        if self.pending is not None:
+            self.pending[0].join()
+            self.pending = None
+        for ev in self.events:
+            if ev is not None:
+                ev.synchronize()
+        key = (str(self.dtype), self.numel)
+        with self._POOL_LOCK:
+            held = sum(t.numel() * t.element_size() for st in self._POOL.values() for t in st)
+            for i, b in enumerate(self.bufs):
+                if b is not None and held + b.numel() * b.element_size() <= self._POOL_MAX_BYTES:
+                    self._POOL.setdefault(key, []).append(b)
+                    held += b.numel() * b.element_size()
+                self.bufs[i] = None
 
     #: helper threads of one block copy (file mapping -> pinned buffer): a single memcpy moves ~2.7 GB/s on the GPU boxes'
     #: hosts, which made the FILE the bottleneck of a file -> WAV run (10 s @ 10 MS/s: 0.148 s, of which ~0.1 s this copy)
@@ -1334,7 +1380,7 @@ class _BlockStager:
     def _fill(self, slot: int, lo: int, hi: int) -> None:
         import threading
 
-        dst = self.bufs[slot].numpy()[: 2 * (hi - lo)]
+        dst = self._buf(slot).numpy()[: 2 * (hi - lo)]
         src = self.frames[2 * lo : 2 * hi]
         parts = min(int(self.copy_threads), max(1, dst.size // (1 << 22)))  # (NumPy copies release the GIL)
         if parts <= 1:
@@ -1372,7 +1418,7 @@ class _BlockStager:
         self.pending = None
         self.slot = slot
         dev = torch.empty(2 * (hi - lo), dtype=self.dtype, device=D.device())
-        dev.copy_(self.bufs[slot][: 2 * (hi - lo)], non_blocking=True)
+        dev.copy_(self._buf(slot)[: 2 * (hi - lo)], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.events[slot] = ev
@@ -1679,13 +1725,11 @@ class MultiChannelPipeline:
             _check_cancel("warm-up")
             for t in targets:  # all probes are enqueued before the first read-back
                 t.begin(warm)
-            # wideband level of the warm-up block as a fraction of full scale (for the precision guard)
-            wide = warm.view(D.torch_mod().float32) if info.fmt == "f32" else warm
-            wide = wide.to(D.torch_mod().float32)
-            if info.fmt == "u8":
-                wide = wide - 128.0
-            wideband_rms = float((wide * wide).mean().sqrt().item()) * math.sqrt(2.0) * P.INGEST_SCALE[info.fmt]
-            del wide
+            # wideband level of the warm-up block as a fraction of full scale (for the precision guard): iqa_raw_level, the
+            # same estimate the batch runners take (eight stretches spread over the block)
+            level = D.zeros(1, "float64")
+            queue_raw_level(warm, info.fmt, level)
+            wideband_rms = wideband_rms_from(float(level.item()), info.fmt)
             for t in targets:
                 t.settle(wideband_rms)
             if cfg.probe_only:
@@ -1789,4 +1833,6 @@ class MultiChannelPipeline:
                         pth.unlink(missing_ok=True)
             raise
         finally:
+            if "stager" in locals():
+                stager.close()
             tracker.close()
