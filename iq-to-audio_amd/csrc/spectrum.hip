@@ -105,6 +105,7 @@ struct PlanCache {
     struct Entry {
         int dev, nfft, batch;
         hipfftHandle handle;
+        hipStream_t last_stream;  // where this plan's most recent transform was enqueued (hipfftSetStream)
     };
     std::mutex mu;
     std::list<Entry> lru;  // front = most recently used
@@ -134,9 +135,17 @@ static int get_plan_locked(PlanCache &c, int nfft, int batch, hipfftHandle *out)
         set_error("hipfftPlanMany(nfft=%d, batch=%d) failed: %d", nfft, batch, static_cast<int>(r));
         return IQA_EHIP;
     }
-    c.lru.push_front({dev, nfft, batch, h});
+    c.lru.push_front({dev, nfft, batch, h, nullptr});
     while (c.lru.size() > PlanCache::kMax) {
-        (void)hipfftDestroy(c.lru.back().handle);  // (its last FFT was enqueued under this lock; rocFFT keeps what it needs)
+        // the evicted plan's last transform may still be running on its stream: wait for that stream before the plan's
+        // work buffers go away (an eviction is rare: more than kMax distinct (nfft, batch) shapes in use)
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        const PlanCache::Entry &old = c.lru.back();
+        if (old.dev != cur) (void)hipSetDevice(old.dev);
+        (void)hipStreamSynchronize(old.last_stream);
+        if (old.dev != cur) (void)hipSetDevice(cur);
+        (void)hipfftDestroy(old.handle);
         c.lru.pop_back();
     }
     *out = h;
@@ -185,6 +194,7 @@ extern "C" int iqa_psd_frames(int32_t fmt, int32_t iq_order, const void *samples
             set_error("hipfftSetStream failed");
             return IQA_EHIP;
         }
+        cache.lru.front().last_stream = s;  // (get_plan_locked moved this plan to the front)
         if (hipfftExecZ2Z(plan, reinterpret_cast<hipfftDoubleComplex *>(work), reinterpret_cast<hipfftDoubleComplex *>(work),
                           HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
             set_error("hipfftExecZ2Z failed");

@@ -680,6 +680,31 @@ def test_channelizer_precision_ladder_against_the_oracle(A):
                 assert rows[(label, p_)][0] < 6.0 * rows[(label, p_)][1], (label, p_, rows[(label, p_)])
     finally:
         PR._ChannelKernel.mfma_min_outputs = keep
+    # the other slot forms: row-staged ring slots (D = 26: the --benchmark rate; "fine" = residue lanes of the rows kernel,
+    # "full" = chained passes of the per-lane kernel) and uint8 captures (D = 25, one data piece: "fine" products are exact)
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 4096
+        for fmt, fs, d in (("s16", 2.5e6, 26), ("u8", 2.4e6, 25)):
+            s16 = O.synth_capture_s16(fs, 1.2, 25e3, seed=5).reshape(-1)
+            raw = s16 if fmt == "s16" else ((s16.astype(np.int32) >> 8) + 128).astype(np.uint8)
+            taps = A.design_channel_filter(fs, 12_500.0, d)
+            z_ref = O.decimate(O.overlap_save(O.nco_mix(O.ingest_to_complex64(raw, fmt), O.NcoState(25e3, fs), 1),
+                                              O.OverlapSaveState(taps, 65536)), O.DecimState(d))
+            dev = D.to_device(raw, "int16" if fmt == "s16" else "uint8")
+            errs = {}
+            for prec in ("fast", "fine", "full"):
+                ch = A.Channelizer(taps, sample_rate=fs, freq_offset=25e3, mix_sign=1, decimation=d, fmt=fmt, precision=prec)
+                z = ch.process(dev).cpu().numpy()
+                errs[prec] = (rms((z - z_ref)[300:-64]), ch.precision, ch._kernel.last_kernel)
+                print(f"precision ladder | {fmt} D={d:3d} | {prec:5s} -> {ch.precision:5s} {ch._kernel.last_kernel:28s}: z rms err {errs[prec][0]:.2e}")
+            assert errs["fast"][2].endswith("_ring") and errs["fine"][2].endswith("_ring")
+            assert errs["fine"][0] * 5.0 < errs["fast"][0] < 2e-5, errs
+            if fmt == "s16":
+                assert errs["full"][1:] == ("full", "k_channelize_mfma_s16") and errs["full"][0] < 5e-8, errs
+            else:
+                assert errs["full"][1] == "fine" and errs["full"][0] == errs["fine"][0], errs
+    finally:
+        PR._ChannelKernel.mfma_min_outputs = keep
     # uint8 captures have no per-lane kernel: "full" is "fine" there; float32 captures have the VALU kernel only
     taps = A.design_channel_filter(2.4e6, 12_500.0, 25)
     assert A.Channelizer(taps, sample_rate=2.4e6, freq_offset=1e5, mix_sign=1, decimation=25, fmt="u8", precision="full").precision == "fine"
