@@ -713,6 +713,59 @@ def test_channelizer_precision_ladder_against_the_oracle(A):
         A.Channelizer(taps, sample_rate=2.4e6, freq_offset=1e5, mix_sign=1, decimation=25, precision="exactly")
 
 
+@pytest.mark.parametrize("precision", ["fine", "full"])
+@pytest.mark.parametrize("fs,d,bw,fmt,order,sign,n", [
+    (10e6, 104, 12_500.0, "s16", "iq", 1, 5_000_000),        # loader waves, one group: two lanes of the multi kernel
+    (20e6, 208, 2_800.0, "s16", "qi_inv", -1, 9_000_000),    # three groups: six lanes in pairs (int32 / 64-bit sums)
+    (20e6, 208, 10_000.0, "s16", "iq_inv", 1, 9_000_000),    # two groups, conjugated sums
+    (5e6, 52, 12_500.0, "s16", "qi", 1, 4_000_000),          # 4 k steps
+    (50e6, 521, 12_500.0, "s16", "iq", -1, 16_000_000),      # row-staged slots, three chained k-step ranges per lane
+    (1.7e6, 18, 12_500.0, "s16", "iq", 1, 3_000_000),        # D % 4 != 0: row-staged, two k steps
+    (2.4e6, 25, 12_500.0, "u8", "iq", 1, 5_000_000),         # uint8: one data piece ("full" is "fine")
+])
+def test_finer_precisions_over_ragged_blocks_and_slot_forms(A, fs, d, bw, fmt, order, sign, n, precision):
+    """Channelizer(precision="fine" / "full") on every slot form of the ring kernels, every iq_order fold and both mixer
+    signs, over TWO ragged blocks (history carry, decimator phase, the float32 edges): against the float32 kernel on the
+    same frames -- at least 5x closer than "fast" on the same capture and within the plan's own prediction."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd import processing as PR
+
+    assert P.choose_decimation(fs, 96_000.0)[0] == d
+    taps = A.design_channel_filter(fs, bw, d)
+    s16 = O.synth_capture_s16(fs, n / fs, 0.11 * fs, seed=9).reshape(-1)
+    raw = s16 if fmt == "s16" else ((s16.astype(np.int32) >> 8) + 128).astype(np.uint8)
+    x = D.to_device(raw, "int16" if fmt == "s16" else "uint8")
+    cut = 2 * (n // 2 + 4_321)
+    keep = PR._ChannelKernel.mfma_min_outputs
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 4096
+
+        def run(prec):
+            ch = A.Channelizer(taps, sample_rate=fs, freq_offset=0.11 * fs, mix_sign=sign, decimation=d, fmt=fmt, iq_order=order, precision=prec)
+            z = torch.cat([ch.process(x[:cut]), ch.process(x[cut:])])
+            return z, ch
+
+        z_ref, _ = run("float32")
+        z_fast, _ = run("fast")
+        z, ch = run(precision)
+    finally:
+        PR._ChannelKernel.mfma_min_outputs = keep
+    assert z.numel() == z_ref.numel() == -(-n // d)
+    settled = slice(64 * (len(taps) // (64 * d) + 2), None)
+    e = float((z - z_ref)[settled].abs().pow(2).mean().sqrt())
+    e_fast = float((z_fast - z_ref)[settled].abs().pow(2).mean().sqrt())
+    wide = rms(s16.astype(np.float64) / 32768.0) * np.sqrt(2.0)
+    pred = ch._kernel.fixed_point_error_rms(wide)
+    print(f"{precision} -> {ch.precision} at fs={fs / 1e6:g} MS/s D={d} {fmt} {order} sign {sign:+d} ({ch._kernel.last_kernel}): "
+          f"z rms err {e:.2e} (fast {e_fast:.2e}, predicted {pred:.2e})")
+    assert ch._kernel.last_kernel.startswith("k_channelize_mfma_")
+    assert e * 5.0 < e_fast and e_fast < 3e-5, (e, e_fast)
+    assert e < 6.0 * pred + 8e-8, (e, pred)  # (+ the float32 grid of z itself: ~3.4e-8 RMS at |z| ~ 0.7, on either side)
+
+
 def test_precision_guard_in_the_batch_runners(A):
     """The benchmarked paths keep the 1e-4 bar on a weak channel too (round-2 finding: they had no guard).  The -70 dBFS
     NFM signal beside a full-scale tone through ResidentCaptureRunner (direct launches and the captured hipGraph step) and
