@@ -667,15 +667,19 @@ def test_resident_capture_runner_batch_and_sign_speculation(A, resident):
     assert np.max(np.abs(r["pcm_host"].numpy().astype(np.int32) - ref48.astype(np.int32))) <= 1
 
 
-@pytest.mark.parametrize("fs,fmt,secs", [(10e6, "s16", 60.0), (20e6, "s16", 60.0), (20e6, "u8", 60.0), (50e6, "s16", 120.0)])
-def test_full_size_capture_windows_match_float32_kernel(A, fs, fmt, secs):
+@pytest.mark.parametrize("fs,fmt,secs,bw,precision", [(10e6, "s16", 60.0, 12_500.0, "fast"), (20e6, "s16", 60.0, 12_500.0, "fast"),
+                                                      (20e6, "u8", 60.0, 12_500.0, "fast"), (50e6, "s16", 120.0, 12_500.0, "fast"),
+                                                      (20e6, "s16", 60.0, 2_800.0, "full"), (10e6, "s16", 60.0, 12_500.0, "fine")])
+def test_full_size_capture_windows_match_float32_kernel(A, fs, fmt, secs, bw, precision):
     """BASELINE's full sizes (config 2: 600 M frames = 2.4 GB; config 4's unit: 1.2 G frames = 4.8 GB of int16, 2.4 GB
     of uint8; config 5: 6 G frames = 24 GB, D = 521, three k-step passes, one of its channels): the matrix-core
     channelizer's output over the whole capture against the float32 VALU kernel run on short slices of it
     (``consumed`` = the slice's position in the capture) -- at the start, around the frames whose byte offsets are
     2^31 ... 2^34 (address and index arithmetic: config 5 has more than 2^32 frames), in the middle and at the very
     end.  A size-independent property: the output at position m depends on frames [m D - L + 1, m D] and on the
-    absolute sample index only."""
+    absolute sample index only.  The last two cases are this at the finer precisions: config 3's SSB filter (32 769 taps,
+    three tap-row groups) at "full" -- six lanes with 64-bit sums in pairs over the 4.8 GB capture -- and config 2 at
+    "fine" (taps + residue lanes of the loader-wave kernel), held to 5e-6 (max) instead of 1e-4."""
     import torch
 
     from iq_to_audio_amd import _dev as D
@@ -685,7 +689,7 @@ def test_full_size_capture_windows_match_float32_kernel(A, fs, fmt, secs):
     f_off = 25e3
     n = int(round(fs * secs))
     d, _ = P.choose_decimation(fs, 96_000.0)
-    taps = A.design_channel_filter(fs, 12_500.0, d)
+    taps = A.design_channel_filter(fs, bw, d)
     ntaps = len(taps)
     unique = O.synth_capture_s16(fs, 0.37, f_off, seed=5)  # 0.37 s: no small period against D or the windows
     if fmt == "u8":
@@ -695,8 +699,9 @@ def test_full_size_capture_windows_match_float32_kernel(A, fs, fmt, secs):
     reps = -(-(n + slack) // (tile.numel() // 2))
     buf = tile.repeat(reps)[: 2 * (n + slack)].contiguous()
     raw = buf[: 2 * n]
-    ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt=fmt)
+    ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, fmt=fmt, precision=precision)
     z = ch.process(raw, last_block=True, halo=(buf, 0))
+    assert ch.precision == precision
     assert ch._kernel.last_kernel == ("k_channelize_mfma_s16_ring" if fmt == "s16" else "k_channelize_mfma_u8_ring")
     n_out = -(-n // d)
     assert z.numel() == n_out
@@ -722,7 +727,8 @@ def test_full_size_capture_windows_match_float32_kernel(A, fs, fmt, secs):
         assert got.numel() == want.numel() and got.numel() >= span // 2
         err = float((got - want).abs().max())
         worst = max(worst, err)
-        assert err < (1e-4 if fmt == "s16" else 2e-4) * max(1.0, float(np.sqrt(ntaps / 6401.0))), (mark, err)
+        bound = (1e-4 if fmt == "s16" else 2e-4) * max(1.0, float(np.sqrt(ntaps / 6401.0))) if precision == "fast" else 5e-6  # (the float32 kernel it is compared with carries up to ~3e-6 itself on 32 769 taps)
+        assert err < bound, (mark, err, precision)
     assert worst > 0.0  # (two different kernels: identical output would mean the comparison compared nothing)
 
 
