@@ -136,7 +136,8 @@ typedef struct {
                                 * its LDS does not depend on outputs_per_block); 64|128 = the ring with 256*S1 + S2
                                 * in one int32, for fragments from a quantisation that bounds that sum
                                 * (dsp_plan.plan_mfma(acc32=True); iqa_mfma_ring_mode(fmt, D, k_first, k_count, 1) != 0);
-                                * bits 0,1,4,5 are timing diagnostics, never set in production */
+                                * bits 0,1,4,5 are timing diagnostics, never set in production; 256 (ring variants) = the
+                                * low tap byte of these fragments is zero throughout: skip its product (as lane bit 1) */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
     void *debug_stamps;        /* NULL in production; diagnostics builds write per-wave cycle stamps here
@@ -198,7 +199,10 @@ typedef struct {
                                  * (256*S1 + S2 per component) themselves; iqa_mfma_combine scales them (raw_scale) */
     int32_t reserved;           /* bit 0: 64-bit sums ((S1 << 32) + S2 per component: fragments WITHOUT the int32 bound, 16-bit
                                  * taps -- dsp_plan.plan_mfma(acc32=False)); the same for every lane of a launch; contiguous
-                                 * slots only, no raw_partials.  See iqa_mfma_ring_lanes. */
+                                 * slots only, no raw_partials.  See iqa_mfma_ring_lanes.
+                                 * bit 1: this lane's LOW tap byte is zero throughout (piece 1 of every fragment: the first
+                                 * lane of a tap-row group under dsp_plan.plan_mfma(residual=True)): the kernel skips the
+                                 * q2*hi product of every k step (two matrix instructions per k step instead of three). */
 } iqa_mfma_lane;
 int iqa_channelize_mfma_multi(int32_t fmt, int32_t decimation, int32_t k_first, int32_t k_count,
                               int32_t outputs_per_block, const iqa_mfma_lane *lanes, int32_t n_lanes,

@@ -330,6 +330,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
     a.raw_partials = 0;
+    a.high_taps_only = (q->reserved & 256) != 0 ? 1 : 0;
     if (ring) {
         return mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2, u8);
     }
@@ -444,6 +445,7 @@ static int channelize_mfma_lanes(int32_t fmt, int32_t decimation, int32_t k_firs
         l.raw_partials = (s.raw_partials != 0 && !s.finalize && !s.partial_in_dev) ? 1 : 0;
         if (s.raw_partials && !l.raw_partials) return fail_inval("raw partials need finalize == 0 and no partial_in");
         if (s.raw_partials && acc64) return fail_inval("raw partials are int32 sums: not with 64-bit sums");
+        l.high_taps_only = (s.reserved & 2) != 0 ? 1 : 0;
     }
     return mfma_ring_launch_multi(a, packed, n_lanes, lds, as_stream(stream), ring_mode == 2, u8, nullptr, pairs, acc64);
 }

@@ -541,7 +541,8 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             const char *la = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT + c.lane_off;
             // The data fragments are read PD k steps ahead by hand (an LDS-DMA is a store to LDS as far as the compiler knows,
             // so it never moves a ds_read above an earlier issue(): the refill in front of this loop is a fence for them).
-            auto tile_body = [&]() {
+            auto tile_body = [&](auto skip_low) {
+                constexpr bool SKIP_LOW = decltype(skip_low)::value;  // q2 == 0 throughout: no q2*hi product
                 constexpr int PD = KS < 2 ? KS : 2;
                 v16i_t acc1, acc2;
                 if constexpr (U8) {
@@ -592,7 +593,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     } else {
                         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], hi, ks ? acc1 : zero16, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], lo, ks ? acc2 : zero16, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
+                        if constexpr (!SKIP_LOW) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
                     }
                     if (IQA_RING_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -608,7 +609,9 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     scatter(t, acc1, acc2);
                 }
             };
-            tile_body();
+            // (a uniform branch: one lane's waves all take the same side)
+            if (!U8 && a.high_taps_only) tile_body(std::true_type{});
+            else tile_body(std::false_type{});
         } else {
             if (STAGGER) asm volatile("s_barrier" ::: "memory");  // no tile this round (odd tile count): the mid-tile barrier alone
             if (emit_now) ring_emit_store<true>(a, c, em, eg);
@@ -768,7 +771,7 @@ struct RingLane {
     unsigned long long rot_step, rot_base;
     double rot64_re, rot64_im;
     float sc_re, sc_im;
-    int col_shift, finalize, conj_sum, rotate, raw_partials;
+    int col_shift, finalize, conj_sum, rotate, raw_partials, high_taps_only;
 };
 
 constexpr int RG_MAX_LANES = 16;  // (<= 5 targets x <= 3 tap-row groups in the reference's CLI; the table travels as kernel arguments)
@@ -809,6 +812,7 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
     a.conj_sum = l.conj_sum;
     a.rotate = l.rotate;
     a.raw_partials = l.raw_partials;
+    a.high_taps_only = l.high_taps_only;
     if constexpr (PAIR) {
         // the pair's first lane has the larger (or the same) tap-row group: ITS stream is staged, the second lane's own
         // tiles arrive 2 rounds per group of difference later; a pair without a second lane (afrag NULL) idles that half
@@ -1149,6 +1153,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         l.conj_sum = s.conj_sum;
         l.rotate = s.rotate;
         l.raw_partials = s.raw_partials;
+        l.high_taps_only = s.high_taps_only;
     }
     for (int i = n_lanes; i < RG_MAX_LANES; ++i) m.lane[i] = m.lane[0];
     const long long ranges = (a.n_out + a.range - 1) / a.range;

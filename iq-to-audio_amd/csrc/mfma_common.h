@@ -35,6 +35,8 @@ struct MfmaArgs {
     float sc_re, sc_im;
     double rot64_re, rot64_im;  // exp(j*2*pi*64*rot_step): rotation between outputs 64 apart (ring kernel emission)
     int raw_partials;  // ring kernels, int32 sums, finalize == 0, no partial_in: partial_out holds int2 {256*S1+S2 re, im} (8 B per output)
+    int high_taps_only;  // ring kernels, int16 data: the low tap byte q2 is zero throughout (the first lane of a "fine" / "full"
+                         // tap-row group, dsp_plan.plan_mfma(residual=True)): the q2*hi MFMA of every k step is skipped
     // lane pairs (ring kernel, two lanes per workgroup): this lane's own tile t is staged in round t + pair_shift (the
     // stream is the one of the pair's lane with the LARGER tap-row group, which starts 2 tiles earlier per group), and
     // the workgroup runs pair_extra rounds beyond a lane's own tiles
@@ -118,7 +120,7 @@ struct MfmaLane {
     unsigned long long rot_step, rot_base;
     double rot64_re, rot64_im;
     float sc_re, sc_im;
-    int col_shift, finalize, conj_sum, rotate, raw_partials;
+    int col_shift, finalize, conj_sum, rotate, raw_partials, high_taps_only;
 };
 int mfma_ring_launch_multi(const MfmaArgs &common, const MfmaLane *lanes, int n_lanes, size_t lds_bytes, hipStream_t stream, bool rows,
                            bool u8, unsigned *blocks_out, bool pairs = false, bool acc64 = false);

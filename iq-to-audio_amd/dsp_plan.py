@@ -178,6 +178,7 @@ class MfmaGroup:
     tq: np.ndarray  # int32 [128, Kpad] quantised taps T = 256*q1 + q2
     q: int = 0  # tap-row group (the data rows a lane of this group streams start 64*q rows earlier)
     residual: bool = False  # the taps of this group are the quantisation residue of the group in front of it
+    high_only: bool = False  # every low tap byte q2 is zero: the ring kernels skip the q2*hi product (two MFMAs per k step)
 
 
 @dataclass
@@ -340,7 +341,7 @@ def plan_mfma(plan: ChannelPlan, acc32: bool = False, max_ksteps: int | None = N
             frag = np.empty((ksteps, 4, 2, 64, 16), dtype=np.int8)
             frag[:, :, 0] = q1.reshape(-1)[flat]
             frag[:, :, 1] = q2.reshape(-1)[flat]
-            groups.append(MfmaGroup(frag, unit, t, q=gi, residual=part == 1))
+            groups.append(MfmaGroup(frag, unit, t, q=gi, residual=part == 1, high_only=bool(s16 and not np.any(q2))))
             for ci in range(n_chunks):
                 k0, k1 = bounds[ci], bounds[ci + 1]
                 sl = t[:, 32 * k0 : 32 * k1]

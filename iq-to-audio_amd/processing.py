@@ -236,7 +236,7 @@ class _ChannelKernel:
                 rng = self._range_max(ps.k_count, variant)
                 self._pass_variant = getattr(self, "_pass_variant", []) + [variant]
                 self.mfma_params.append(N.MfmaParams(
-                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.acc32) else 0), unit=mp.groups[ps.group].unit / (256.0 if self.plan.fmt == "u8" else 1.0), c_re=ps.c_re,
+                    outputs_per_block=rng, reserved=self._VARIANT[variant][0] | (128 if (variant == "ring" and self.acc32) else 0) | (256 if (variant == "ring" and mp.groups[ps.group].high_only) else 0), unit=mp.groups[ps.group].unit / (256.0 if self.plan.fmt == "u8" else 1.0), c_re=ps.c_re,
                     c_im=ps.c_im, debug_stamps=None, q_group=mp.groups[ps.group].q, k_first=ps.k_first, k_count=ps.k_count,
                     finalize=0, partial_in_dev=None, partial_out_dev=None))
         return self.mfma
@@ -778,7 +778,7 @@ class ChannelBank:
                     lane.q_group, lane.finalize = mp.groups[gi].q, int(fin)
                     lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
                     lane.raw_partials = int(raw and not fin)
-                    lane.reserved = 0 if acc32 else 1  # (bit 0: 64-bit sums)
+                    lane.reserved = (0 if acc32 else 1) | (2 if mp.groups[gi].high_only else 0)  # (bit 0: 64-bit sums; bit 1: q2 == 0)
                 N.call(entry, c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first), c_int32(k_count), c_int32(rng),
                        table, c_int32(len(part)), N.ptr(big), c_int64(big_frames), c_int64(big_consumed), c_int64(m_a), c_int64(n_int),
                        N.stream_ptr())
