@@ -609,6 +609,7 @@ class ChannelBank:
     """
 
     MAX_LANES = 16  # per launch (the lane table travels as kernel arguments)
+    skip_zero_low_taps = bool(int(__import__("os").environ.get("IQA_SKIP_ZERO_LOW_TAPS", "1")))  # (A/B switch for profiles/)
     pair_lanes = True  # two lanes of equal tap-row group per workgroup where the kernel offers it (see _run_shared)
 
     def __init__(self, channelizers: list):
@@ -778,7 +779,7 @@ class ChannelBank:
                     lane.q_group, lane.finalize = mp.groups[gi].q, int(fin)
                     lane.conj_sum, lane.rotate = k.params.conj_sum, k.params.rotate
                     lane.raw_partials = int(raw and not fin)
-                    lane.reserved = (0 if acc32 else 1) | (2 if mp.groups[gi].high_only else 0)  # (bit 0: 64-bit sums; bit 1: q2 == 0)
+                    lane.reserved = (0 if acc32 else 1) | (2 if (mp.groups[gi].high_only and self.skip_zero_low_taps) else 0)  # (bit 0: 64-bit sums; bit 1: q2 == 0)
                 N.call(entry, c_int32(P.FMT_CODE[self.fmt]), c_int32(self.decimation), c_int32(k_first), c_int32(k_count), c_int32(rng),
                        table, c_int32(len(part)), N.ptr(big), c_int64(big_frames), c_int64(big_consumed), c_int64(m_a), c_int64(n_int),
                        N.stream_ptr())
