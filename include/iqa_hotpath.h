@@ -136,8 +136,8 @@ typedef struct {
                                 * its LDS does not depend on outputs_per_block); 64|128 = the ring with 256*S1 + S2
                                 * in one int32, for fragments from a quantisation that bounds that sum
                                 * (dsp_plan.plan_mfma(acc32=True); iqa_mfma_ring_mode(fmt, D, k_first, k_count, 1) != 0);
-                                * bits 0,1,4,5 are timing diagnostics, never set in production; 256 (ring variants) = the
-                                * low tap byte of these fragments is zero throughout: skip its product (as lane bit 1) */
+                                * bits 0,1,4,5 are timing diagnostics, never set in production; 256 = the low tap byte
+                                * of these fragments is zero throughout (a hint: the multi-lane launches act on it, lane bit 1) */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */
     void *debug_stamps;        /* NULL in production; diagnostics builds write per-wave cycle stamps here

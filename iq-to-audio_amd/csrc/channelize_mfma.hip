@@ -330,7 +330,7 @@ extern "C" int iqa_channelize_mfma(const iqa_chan_params *p, const iqa_mfma_para
         a.rot64_im = std::sin(2.0 * M_PI * turns);
     }
     a.raw_partials = 0;
-    a.high_taps_only = (q->reserved & 256) != 0 ? 1 : 0;
+    a.high_taps_only = 0;  // (single-lane launches always compute the q2*hi product: reserved bit 8 is accepted and ignored)
     if (ring) {
         return mfma_ring_launch(a, static_cast<unsigned>(blocks), lds, as_stream(stream), ring_mode == 2, u8);
     }

@@ -101,6 +101,19 @@ constexpr int RG_PACE_SPINS = 20000;
 constexpr int RG_PACE_WORDS = 16384;       // words of the pacing buffer: ranges x units of a launch must fit
 constexpr int RG_PAIR_IDLE = 1 << 28;  // MfmaArgs::pair_shift of the half of a pair that has no lane
 
+// One LDS-DMA instruction: 64 lanes x 16 bytes, global -> LDS (global_load_lds_dwordx4).  The 16-byte form exists on
+// gfx950 only; the HOST pass of the compilation checks the builtin's size argument against ITS target and, inside
+// function templates, turns that into spurious "no matching function" errors -- it never needs the body.
+__device__ __forceinline__ void ring_dma16(const void *src, ring_lds_t *dst)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, IQA_RING_DMA_AUX);
+#else
+    (void)src;
+    (void)dst;
+#endif
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void *)p));
@@ -327,11 +340,11 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
         if constexpr (ROWS) {
 #pragma unroll
             for (int i = 0; i < G::NI_ROWS; ++i)
-                __builtin_amdgcn_global_load_lds(src + soff[i], (ring_lds_t *)(dst + i * 1024), 16, 0, IQA_RING_DMA_AUX);
+                ring_dma16(src + soff[i], (ring_lds_t *)(dst + i * 1024));
         } else {
 #pragma unroll
             for (int i = 0; i < G::NI; ++i)
-                __builtin_amdgcn_global_load_lds(src + soff[i], (ring_lds_t *)(dst + i * 1024), 16, 0, IQA_RING_DMA_AUX);
+                ring_dma16(src + soff[i], (ring_lds_t *)(dst + i * 1024));
         }
     };
     if (STREAM) {
@@ -374,9 +387,13 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
 // DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
-template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER, bool PAIR = false>
-__device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2])
+// SKIP: what this wave does with the q2*hi product (the third matrix instruction of a k step): 0 = always computes it;
+// 2 = never (its lane's low tap byte is zero throughout: the first lane of a "fine" / "full" tap-row group); 1 = asks the
+// lane's flag at run time (both bodies in the code: ~30 registers more, so only the kernels of such launches carry it).
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER, bool PAIR, typename SKIPT>
+__device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2], SKIPT)
 {
+    constexpr int SKIP = SKIPT::value;
     using G = RingGeo<KS, ROWS, U8, PAIR>;
     constexpr int R = G::R, SLOT = G::SLOT;
     static_assert(!(ROWS && ISSUER), "row-staged slots are always fed by loader waves");
@@ -406,9 +423,9 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         char *slot0 = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT;
         const int at = (i < KS) ? odd_kib + i * 2048 : 2 * KS * 1024;  // instruction numbers p, p + 2, ..., then 2*KS
         if constexpr (ISSUER && G::PADDED) {
-            __builtin_amdgcn_global_load_lds(tile0 + soff[i], (ring_lds_t *)(slot0 + at), 16, 0, IQA_RING_DMA_AUX);
+            ring_dma16(tile0 + soff[i], (ring_lds_t *)(slot0 + at));
         } else {
-            __builtin_amdgcn_global_load_lds(tile0 + soff[0] + at, (ring_lds_t *)(slot0 + at), 16, 0, IQA_RING_DMA_AUX);
+            ring_dma16(tile0 + soff[0] + at, (ring_lds_t *)(slot0 + at));
         }
     };
     if (STREAM) {
@@ -609,9 +626,14 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     scatter(t, acc1, acc2);
                 }
             };
-            // (a uniform branch: one lane's waves all take the same side)
-            if (!U8 && a.high_taps_only) tile_body(std::true_type{});
-            else tile_body(std::false_type{});
+            if constexpr (SKIP == 2 && !U8) {
+                tile_body(std::true_type{});
+            } else if constexpr (SKIP == 1 && !U8) {  // (a uniform branch: one lane's waves all take the same side)
+                if (a.high_taps_only) tile_body(std::true_type{});
+                else tile_body(std::false_type{});
+            } else {
+                tile_body(std::false_type{});
+            }
         } else {
             if (STAGGER) asm volatile("s_barrier" ::: "memory");  // no tile this round (odd tile count): the mid-tile barrier alone
             if (emit_now) ring_emit_store<true>(a, c, em, eg);
@@ -640,7 +662,10 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 
 // One block = one contiguous range of outputs of any length (the host gives every CU one range): a persistent
 // stream through the ring, sums in a 512-position sliding window, outputs emitted two rounds behind the matrix work.
-template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool PAIR = false>
+// SKIPK (kernels of launches in which some lanes have high-byte-only taps, see ring_main's SKIP): lane pairs -- the pair's
+// first lane (parity 0) skips the q2*hi product at compile time, the second never does (the host pairs a tap-row group's
+// high-byte lane with its residue lane); one lane per workgroup -- every wave asks its lane's flag.
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool PAIR = false, bool SKIPK = false>
 __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_idx)
 {
     using G = RingGeo<KS, ROWS, U8, PAIR>;
@@ -705,21 +730,25 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
         // round as without pairs); one wave of either parity emits ITS lane's outputs; parity 1 defers its adds
         // (waves go to SIMDs cyclically: issuers on SIMDs 0 and 1, lane A's emitter -- wave 2 -- on SIMD 2, lane B's -- wave
         // 7 -- on SIMD 3)
-        if (c.cp == 0 && c.rt < 2) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, true>(a, c, fq);
-        else if (c.rt == 2 + c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq);
-        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq);
+        constexpr int SA = SKIPK ? 2 : 0, SB = 0;  // (parity 0 = the pair's first lane)
+        if (c.cp == 0 && c.rt < 2) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
+        else if (c.cp == 0 && c.rt == 2) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq, std::integral_constant<int, SA>{});
+        else if (c.cp == 1 && c.rt == 3) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq, std::integral_constant<int, SB>{});
+        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, true>(a, c, fq, std::integral_constant<int, SB>{});
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
     } else if constexpr (LOADERS) {
-        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false>(a, c, fq);
+        constexpr int S1 = SKIPK ? 1 : 0;
+        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, false>(a, c, fq, std::integral_constant<int, S1>{});
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, false>(a, c, fq, std::integral_constant<int, S1>{});
     } else {
+        constexpr int S1 = SKIPK ? 1 : 0;
         // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
         if ((c.rt >> 1) == c.cp) {
-            if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, true>(a, c, fq);
-            else ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false>(a, c, fq);
-        } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false>(a, c, fq);
-        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true>(a, c, fq);
-        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false>(a, c, fq);
+            if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, true, false>(a, c, fq, std::integral_constant<int, S1>{});
+            else ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, false>(a, c, fq, std::integral_constant<int, S1>{});
+        } else if (wave == RG_EMIT_WAVE) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, false>(a, c, fq, std::integral_constant<int, S1>{});
+        else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, false>(a, c, fq, std::integral_constant<int, S1>{});
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, false>(a, c, fq, std::integral_constant<int, S1>{});
     }
 }
 
@@ -782,7 +811,7 @@ struct RingMultiArgs {
     RingLane lane[RG_MAX_LANES];
 };
 
-template <int KS, bool ROWS, bool U8, bool PAIR = false, bool ACC64 = false>
+template <int KS, bool ROWS, bool U8, bool PAIR = false, bool ACC64 = false, bool SKIPK = false>
 __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
 {
     const int idx = blockIdx.x >> 3;
@@ -828,28 +857,28 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
         a.pace_slot = static_cast<int>(range_idx) * units + idx % units;
     }
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
-    ring_block<KS, 0, ACC64, ROWS, U8, PAIR>(a, range_idx);
+    ring_block<KS, 0, ACC64, ROWS, U8, PAIR, SKIPK>(a, range_idx);
 }
 
 // ACC64: one int64 (S1 << 32) + S2 per output component instead of one int32 256*S1 + S2 -- 16-bit taps without the int32
 // bound, what the "full" precision's lanes (taps + their residue, dsp_plan.plan_mfma(residual=True)) need; contiguous slots only.
-template <int KS, bool ACC64 = false>
+template <int KS, bool ACC64 = false, bool SKIPK = false>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_multi(RingMultiArgs m)
 {
-    ring_multi_block<KS, false, false, false, ACC64>(m);
+    ring_multi_block<KS, false, false, false, ACC64, SKIPK>(m);
 }
 
 // Two lanes per workgroup (RingGeo PAIR): the lanes of the table in pairs of equal tap-row group.
-template <int KS, bool ACC64 = false>
+template <int KS, bool ACC64 = false, bool SKIPK = false>
 __global__ __launch_bounds__((RingGeo<KS, false, false, true>::THREADS), 2) void k_channelize_mfma_s16_ring_pairs(RingMultiArgs m)
 {
-    ring_multi_block<KS, false, false, true, ACC64>(m);
+    ring_multi_block<KS, false, false, true, ACC64, SKIPK>(m);
 }
 
-template <int KS>
+template <int KS, bool SKIPK = false>
 __global__ __launch_bounds__((RingGeo<KS, true>::THREADS), 3) void k_channelize_mfma_s16_ring_rows_multi(RingMultiArgs m)
 {
-    ring_multi_block<KS, true, false>(m);
+    ring_multi_block<KS, true, false, false, false, SKIPK>(m);
 }
 
 template <int KS>
@@ -908,19 +937,23 @@ static int ring_launch_rows_u8(const MfmaArgs &a, unsigned blocks, size_t lds, h
 }
 
 template <int KS>
-static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8, bool acc64)
+static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8, bool acc64, bool skipk)
 {
-    static std::atomic<unsigned long long> done[4] = {{0}, {0}, {0}, {0}};
+    static std::atomic<unsigned long long> done[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
     if (acc64) {
         if constexpr (KS < RG_MAX_KS) {  // (64-bit sums at 16 k steps do not fit the registers)
-            if (!rows && !u8)
+            if (!rows && !u8) {
+                if (skipk)
+                    return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS, true, true>, "k_channelize_mfma_s16_ring_multi64", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[4]);
                 return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS, true>, "k_channelize_mfma_s16_ring_multi64", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[3]);
+            }
         }
         set_error("multi-lane launches with 64-bit sums: contiguous int16 slots, at most %d k steps (got %d)", RG_MAX_KS - 1, KS);
         return IQA_EINVAL;
     }
     if constexpr (KS <= RG_ROWS_MAX_KS_C) {
         if (u8) return ring_launch_kernel(k_channelize_mfma_u8_ring_rows_multi<KS>, "k_channelize_mfma_u8_ring_rows_multi", RingGeo<KS, true, true>::THREADS, m, blocks, lds, stream, done[2]);
+        if (rows && skipk) return ring_launch_kernel(k_channelize_mfma_s16_ring_rows_multi<KS, true>, "k_channelize_mfma_s16_ring_rows_multi", RingGeo<KS, true>::THREADS, m, blocks, lds, stream, done[5]);
         if (rows) return ring_launch_kernel(k_channelize_mfma_s16_ring_rows_multi<KS>, "k_channelize_mfma_s16_ring_rows_multi", RingGeo<KS, true>::THREADS, m, blocks, lds, stream, done[1]);
     } else {
         if (u8 || rows) {
@@ -928,23 +961,28 @@ static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds
             return IQA_EINVAL;
         }
     }
+    if (skipk) return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS, false, true>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[6]);
     return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[0]);
 }
 
 constexpr int RG_PAIR_MIN_KS = IQA_RING_LOADERS_MAX_KS + 1;  // lane pairs where the single-lane kernel runs without loader waves
 
 template <int KS>
-static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_t stream, bool acc64)
+static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_t stream, bool acc64, bool skipk)
 {
-    static std::atomic<unsigned long long> done{0}, done64{0};
+    static std::atomic<unsigned long long> done{0}, done64{0}, done_s{0}, done64_s{0};
     if constexpr (KS >= RG_PAIR_MIN_KS) {
         using G = RingGeo<KS, false, false, true>;
         if (acc64) {
-            if constexpr (KS <= 14)
+            if constexpr (KS <= 14) {
+                if (skipk)
+                    return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS, true, true>, "k_channelize_mfma_s16_ring_pairs64", G::THREADS, m, blocks, G::LDS_BYTES, stream, done64_s);
                 return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS, true>, "k_channelize_mfma_s16_ring_pairs64", G::THREADS, m, blocks, G::LDS_BYTES, stream, done64);
+            }
             set_error("lane pairs with 64-bit sums: 9..14 k steps (got %d)", KS);
             return IQA_EINVAL;
         }
+        if (skipk) return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS, false, true>, "k_channelize_mfma_s16_ring_pairs", G::THREADS, m, blocks, G::LDS_BYTES, stream, done_s);
         return ring_launch_kernel(k_channelize_mfma_s16_ring_pairs<KS>, "k_channelize_mfma_s16_ring_pairs", G::THREADS, m, blocks, G::LDS_BYTES, stream, done);
     } else {
         set_error("lane pairs need at least %d k steps (got %d)", RG_PAIR_MIN_KS, KS);
@@ -1156,6 +1194,22 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         l.high_taps_only = s.high_taps_only;
     }
     for (int i = n_lanes; i < RG_MAX_LANES; ++i) m.lane[i] = m.lane[0];
+    // Which lanes may skip the q2*hi product.  Pairs: the kernel variant skips it for every pair's FIRST lane at compile time,
+    // so it is taken only when every first lane is high-byte-only and no second lane is (what the host's pairing of a
+    // tap-row group's two lanes gives); otherwise nothing is skipped.  One lane per workgroup: the variant that asks the
+    // lane's flag, when any lane has it.
+    bool skipk = false;
+    if (!u8) {
+        if (pairs) {
+            skipk = true;
+            for (int i = 0; i < n_lanes; i += 2)
+                if (!lanes[i].high_taps_only || (lanes[i + 1].afrag != nullptr && lanes[i + 1].high_taps_only)) skipk = false;
+        } else {
+            for (int i = 0; i < n_lanes; ++i) skipk = skipk || lanes[i].high_taps_only != 0;
+        }
+    }
+    if (!skipk)
+        for (int i = 0; i < RG_MAX_LANES; ++i) m.lane[i].high_taps_only = 0;
     const long long ranges = (a.n_out + a.range - 1) / a.range;
     const long long groups = (ranges + 7) / 8;  // ranges are dealt to the 8 XCD classes: workgroup b -> class b % 8
     const unsigned blocks = static_cast<unsigned>(groups * (pairs ? n_lanes / 2 : n_lanes) * 8);
@@ -1164,7 +1218,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         m.c.pace = nullptr;
         m.c.pace = ring_pace_buffer(m.c.pace_token, static_cast<int>(std::min<long long>(groups * 8 * (n_lanes / 2), RG_PACE_WORDS + 1)), stream);
         switch (a.ksteps) {
-#define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream, acc64)
+#define RG_PAIRS(K) case K: return ring_launch_pairs<K>(m, blocks, stream, acc64, skipk)
             RG_PAIRS(9); RG_PAIRS(10); RG_PAIRS(11); RG_PAIRS(12); RG_PAIRS(13); RG_PAIRS(14); RG_PAIRS(16);
 #undef RG_PAIRS
             default: break;
@@ -1173,7 +1227,7 @@ int mfma_ring_launch_multi(const MfmaArgs &a, const MfmaLane *lanes, int n_lanes
         return IQA_EINVAL;
     }
     switch (a.ksteps) {
-#define RG_MULTI(K) case K: return ring_launch_multi<K>(m, blocks, lds, stream, rows, u8, acc64)
+#define RG_MULTI(K) case K: return ring_launch_multi<K>(m, blocks, lds, stream, rows, u8, acc64, skipk)
         RG_MULTI(1); RG_MULTI(2); RG_MULTI(3); RG_MULTI(4); RG_MULTI(5); RG_MULTI(6); RG_MULTI(7); RG_MULTI(8);
         RG_MULTI(9); RG_MULTI(10); RG_MULTI(11); RG_MULTI(12); RG_MULTI(13); RG_MULTI(14); RG_MULTI(15); RG_MULTI(16);
 #undef RG_MULTI

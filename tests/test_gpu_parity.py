@@ -820,6 +820,57 @@ def test_resident_capture_runner_other_modes_and_rates(A, mode, agc, fs, bw):
     assert abs(r["demod"].peak - want.audio_peak) < 1e-4
 
 
+@pytest.mark.parametrize("fs,bw", [(2.5e6, 2_800.0), (20e6, 2_800.0)])
+def test_batch_runners_run_ssb_with_agc_at_full_precision(A, fs, bw):
+    """SSB with the AGC on through the batch path -- ResidentCaptureRunner (direct launches and the captured hipGraph step)
+    and ResidentBankRunner -- at the reference's --benchmark rate (D = 26: chained passes of the per-lane kernel) and at
+    config 3's (D = 208: lanes with 64-bit sums): the runners pick the "full" precision themselves
+    (processing.base_precision), z within 3e-7 of the oracle's, and the audio is what the float64 statement of the decoder
+    makes of that very z on EVERY sample (the logic link of DESIGN.md section 5: a wrong restart index or state hand-off
+    shows at the 1e-2 level)."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import dsp_plan as P
+    from iq_to_audio_amd.batch import ResidentBankRunner, ResidentCaptureRunner
+    from test_gpu_configs import chunk_lens_for, oracle_ssb_f64_chunks
+
+    f_off, secs = 25e3, 1.1 if fs < 5e6 else 0.5
+    d, fs_ch = P.choose_decimation(fs, 96_000.0)
+    chunk = P.tune_chunk_size(fs, 1_048_576)
+    taps = A.design_channel_filter(fs, bw, d)
+    n = int(round(fs * secs))
+    cap = O.synth_capture_s16(fs, secs, f_off, seed=11)
+    want = O.run_chain(cap, sample_rate=fs, freq_offset=f_off, bandwidth=bw, demod_mode="usb", agc_enabled=True)
+    lens = chunk_lens_for(n, chunk, d, want.decimated.size)
+    _, slack = ResidentCaptureRunner.padded_capture_frames(d, len(taps))
+    buf = torch.zeros(2 * (n + slack), dtype=torch.int16, device=D.device())
+    buf[: 2 * n] = D.to_device(cap.reshape(-1), "int16")
+    raw = buf[: 2 * n]
+    torch.cuda.synchronize()
+
+    def check(label, r):
+        z, audio = r["z"].cpu().numpy(), r["audio"].cpu().numpy()
+        assert r["precision"] == "full" and r["sign"] == want.mix_sign, label
+        assert z.size == want.decimated.size and audio.size == want.audio.size, label
+        dz = rms(z - want.decimated)
+        logic = np.abs(audio.astype(np.float64) - oracle_ssb_f64_chunks(z, lens, "usb")).max()
+        print(f"SSB+AGC through {label} at {fs / 1e6:g} MS/s: z rms diff {dz:.2e}, logic max {logic:.2e}")
+        assert dz < 3e-7 and logic < 1e-5, (label, dz, logic)
+
+    runner = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk,
+                                   n_frames=n, demod_mode="usb", agc_enabled=True)
+    assert runner.base_precision == "full"
+    check("ResidentCaptureRunner.submit", runner.collect(runner.submit(raw, enclosing=buf, lead_frames=0)))
+    for _ in range(2):  # capture, then replay
+        check("ResidentCaptureRunner.submit_captured", runner.collect(runner.submit_captured(raw, enclosing=buf, lead_frames=0)))
+    bank = ResidentBankRunner([dict(freq_offset=f_off, demod_mode="usb", bandwidth=bw), dict(freq_offset=f_off, demod_mode="nfm")],
+                              sample_rate=fs, n_frames=n)
+    res = bank.collect(bank.submit(raw, enclosing=buf, lead_frames=0))
+    check("ResidentBankRunner", res[0])
+    assert res[1]["precision"] == "fast"
+
+
 def test_pipeline_cancel_removes_partial_output(A, tmp_path):
     """reference tests/test_processing.py:125-151: cancelling raises ProcessingCancelled and leaves no file."""
     from iq_to_audio_amd import iqio
