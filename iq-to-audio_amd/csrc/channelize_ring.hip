@@ -68,6 +68,15 @@
 #ifndef IQA_RING_ROUNDS_MAX
 #define IQA_RING_ROUNDS_MAX 5  // ring depth of the single-lane kernels in rounds of two tiles, where LDS allows it
 #endif
+// Lane pairs: data tiles per round.  1 (default): one tile per round, two issuing waves (RingGeo PAIR below).  2: a round is
+// TWO tiles and every wave multiplies both with its lane's tap rows -- half as many round barriers per tile, the ring fed
+// exactly as in the single-lane kernel (one issuing wave per SIMD), one emitting wave per lane every round.  Built,
+// bit-identical on every pair test, and MEASURED SLOWER on config 3 (same box, alternating: 9.12 against 8.78 ms with
+// every target "fast", 14.15 against 13.67 ms at the product's precisions; profiles/r03_ab_pair_tiles.txt): the round
+// barrier is not what the pair kernel waits for (the probe said the same).  A/B knob only.
+#ifndef IQA_RING_PAIR_TILES
+#define IQA_RING_PAIR_TILES 1
+#endif
 #ifndef IQA_RING_PAIR_ROUNDS
 #define IQA_RING_PAIR_ROUNDS 3  // ring depth of the lane-pair kernel in rounds (2..5).  Its speed does not depend on it (2, 3, 5:
                                 // 9.19 / 9.08 / 9.08 ms at config 3); at 3 a workgroup leaves 59 KB of a CU's LDS to the small
@@ -144,7 +153,9 @@ template <int KS, bool ROWS, bool U8 = false, bool PAIR = false>
 struct RingGeo {
     static_assert(ROWS || !U8, "uint8 captures use row-staged slots");
     static_assert(!PAIR || (!ROWS && !U8), "lane pairs: contiguous slots only");
-    static constexpr int TPR = PAIR ? 1 : 2;   // tiles per round
+    static constexpr bool PAIR1 = PAIR && IQA_RING_PAIR_TILES == 1;  // lane pairs, one tile per round
+    static constexpr bool PAIR2 = PAIR && IQA_RING_PAIR_TILES != 1;  // lane pairs, two tiles per round (every wave takes both)
+    static constexpr int TPR = PAIR1 ? 1 : 2;  // tiles per round
     static constexpr int ACCS = PAIR ? 2 : 1;  // windows of sums
     static constexpr int KBYTES = U8 ? 32 : 64;  // bytes of a row per k step
     static constexpr int PITCH = KBYTES * KS + 16;
@@ -179,6 +190,7 @@ struct RingCtx {
     int tiles, rounds, cnt, lane_off, rt, cp, col, h, lane;
     int row_units, pitch_units;  // contiguous slots: 16-byte units per data row in the capture / in LDS (odd)
     int tshift;  // lane pairs: this wave's own tile t is the staged tile of round t + tshift (0 without pairs)
+    int extra;   // lane pairs: rounds the workgroup runs beyond a lane's own tiles (the second lane works that far behind)
 };
 
 // Source offset (bytes from the tile's first byte) of the 16 bytes lane `lane` of DMA instruction `idx` fetches: the
@@ -400,7 +412,12 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     // PAIR: round r works on tile r (both parities: two lanes' tap rows), whose slot is ring slot r mod R; a lane's group k
     // of 64 outputs (tiles 2k, 2k + 1) is emitted by that lane's emitting wave in round 2k + 5 (parity 0) / 2k + 6 (parity
     // 1): the two lanes' emissions fall into alternate rounds
-    const int RG_EMIT_LAG_PAIR = 5 + c.cp;
+    const int RG_EMIT_LAG_PAIR = 5 + c.cp;  // (PAIR1 only)
+    constexpr bool PAIR1 = G::PAIR1, PAIR2 = G::PAIR2;
+    // PAIR2: a round is tiles 2r, 2r + 1 of the STAGED stream (the pair's first lane's), in slots 2 * slot + j like the
+    // single-lane kernel's; every wave multiplies both with its lane's tap rows; a lane's own tiles are the staged ones of
+    // tshift rounds earlier (one round per tap-row group of difference), its group k of 64 outputs is the two tiles of its
+    // round k and is emitted by the lane's emitting wave in round k + RG_EMIT_LAG of that lane's count, every round.
     constexpr bool STREAM = ISSUER && !(DBG & 16);
     const int rt = c.rt, cp = c.cp;
     // the two issuing waves of a parity share the tile's 2*KS + 1 DMA instructions: wave p = rt & 1 issues numbers
@@ -419,8 +436,8 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     const int odd_kib = (rt & 1) * 1024;
     auto issue = [&](int tile, int slot, int i) {  // `i` is a compile-time constant at every call site
         // (PAIR: the stream runs on past this lane's own last tile for the partner that works pair_extra rounds behind)
-        const char *tile0 = c.stream0 + static_cast<long long>(min(tile, (PAIR ? c.rounds : c.tiles) - 1)) * c.tile_bytes;
-        char *slot0 = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT;
+        const char *tile0 = c.stream0 + static_cast<long long>(min(tile, (PAIR1 ? c.rounds : PAIR2 ? c.tiles + 2 * c.extra : c.tiles) - 1)) * c.tile_bytes;
+        char *slot0 = c.smem + (PAIR1 ? slot : slot * 2 + cp) * SLOT;
         const int at = (i < KS) ? odd_kib + i * 2048 : 2 * KS * 1024;  // instruction numbers p, p + 2, ..., then 2*KS
         if constexpr (ISSUER && G::PADDED) {
             ring_dma16(tile0 + soff[i], (ring_lds_t *)(slot0 + at));
@@ -432,7 +449,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
         for (int rr = 0; rr < R - 1; ++rr)
 #pragma unroll
-            for (int i = 0; i <= KS; ++i) issue(PAIR ? rr : 2 * rr + cp, rr, i);
+            for (int i = 0; i <= KS; ++i) issue(PAIR1 ? rr : 2 * rr + cp, rr, i);
     }
     RingEmit em{1.0, 0.0};
     if (EMIT && a.finalize && a.rotate) {
@@ -484,7 +501,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     // DBG & 2 (diagnostic builds): per wave, cycles spent waiting in front of / at the round barrier and cycles between
     // barriers, summed over the rounds -> a.stamps[(workgroup * 8 + wave) * 4 + {0: wait, 1: work, 2: rounds, 3: first tile stamp}]
     unsigned long long st_wait = 0, st_work = 0, st_prev = 0;
-    bool pace_on = PAIR && a.pace != nullptr && a.pace_units > 1 && c.rounds < 8000;
+    bool pace_on = PAIR && a.pace != nullptr && a.pace_units > 1 && c.rounds < (PAIR2 ? 4000 : 8000);  // (12 bits of publication count)
     for (int r = 0; r < c.rounds; ++r) {
         unsigned long long st0 = 0;
         if (DBG & 2) {
@@ -505,8 +522,8 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             // the capture in HBM reads.  So every second round a workgroup publishes its round and the one that is more
             // than RG_PACE_AHEAD publications in front of the slowest STARTED workgroup of its range waits for it -- the
             // slowest never waits, a workgroup that has not started is not waited for: no cycle.
-            if (c.rt == 3 && pace_on && (r & 1) == 0) {
-                const unsigned int mine = static_cast<unsigned int>(r >> 1);
+            if (c.rt == 3 && c.cp == 0 && pace_on && (PAIR2 || (r & 1) == 0)) {  // (every second tile either way)
+                const unsigned int mine = static_cast<unsigned int>(PAIR2 ? r : r >> 1);
                 if (c.lane == 0) __hip_atomic_store(a.pace + a.pace_slot, (a.pace_token << 12) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int spin = 0;; ++spin) {
                     unsigned int q = mine;
@@ -528,7 +545,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             }
         }
         const bool pf = STREAM && (r + R - 1 < c.rounds);
-        const int pf_tile = PAIR ? r + R - 1 : 2 * (r + R - 1) + cp;
+        const int pf_tile = PAIR1 ? r + R - 1 : 2 * (r + R - 1) + cp;
         const int pf_slot = (slot == 0) ? R - 1 : slot - 1;  // the slot round r-1 has just left
         // The refill of that slot goes out FIRST, all KS + 1 instructions of it, before this round's matrix work: at
         // 13 k steps the ring holds two rounds only, so a DMA issued late in round r (one per k step, as this loop used
@@ -539,23 +556,29 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 #pragma unroll
             for (int i = 0; i <= KS; ++i) issue(pf_tile, pf_slot, i);
         }
-        const int re = r - c.tshift;  // PAIR: the round in this lane's own count (its tile re is staged now)
-        const bool emit_now = EMIT && (PAIR ? (re >= RG_EMIT_LAG_PAIR && ((re - RG_EMIT_LAG_PAIR) & 1) == 0) : r >= RG_EMIT_LAG);
+        const int re = r - c.tshift;  // PAIR: the round in this lane's own count (its tile(s) of round re are staged now)
+        const bool emit_now = EMIT && (PAIR1 ? (re >= RG_EMIT_LAG_PAIR && ((re - RG_EMIT_LAG_PAIR) & 1) == 0) : re >= RG_EMIT_LAG);
         RingEmitRegs eg;
         if (emit_now) {
             asm volatile("" ::: "memory");
             // see ring_loader for why these sums are final (PAIR: the group's last tile was round r - 4's, whose adds --
             // deferred by one round at most -- went out before the barrier of round r - 2)
-            ring_emit_load<ACC64, true>(a, c, PAIR ? (re - RG_EMIT_LAG_PAIR) >> 1 : r - RG_EMIT_LAG, eg);
+            ring_emit_load<ACC64, true>(a, c, PAIR1 ? (re - RG_EMIT_LAG_PAIR) >> 1 : re - RG_EMIT_LAG, eg);
             asm volatile("" ::: "memory");
         }
         if (DEFER_ADDS && held_t >= 0) {
             scatter(held_t, held1, held2);
             held_t = -1;
         }
-        const int t = PAIR ? re : 2 * r + cp;
+        bool store_pending = emit_now;  // the emitting wave finishes its group inside its first tile of the round
+        constexpr int NTW = PAIR2 ? 2 : 1;  // tiles this wave multiplies per round
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+        const int t = PAIR1 ? re : PAIR2 ? 2 * re + j : 2 * r + cp;
         if (t >= 0 && t < c.tiles) {
-            const char *la = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT + c.lane_off;
+            const bool store_here = store_pending;
+            store_pending = false;
+            const char *la = c.smem + (PAIR1 ? slot : PAIR2 ? slot * 2 + j : slot * 2 + cp) * SLOT + c.lane_off;
             // The data fragments are read PD k steps ahead by hand (an LDS-DMA is a store to LDS as far as the compiler knows,
             // so it never moves a ds_read above an earlier issue(): the refill in front of this loop is a fence for them).
             auto tile_body = [&](auto skip_low) {
@@ -590,7 +613,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 for (int ks = 0; ks < KS; ++ks) {
                     // the other parity's tile boundary: no memory clobber -- this wave's own fragment reads may move across it
                     if (STAGGER && ks == KS / 2) asm volatile("s_barrier");
-                    if (EMIT && ks == KS - 3 && emit_now) ring_emit_store<true>(a, c, em, eg);  // (its reads went out before k step 0)
+                    if (EMIT && ks == KS - 3 && store_here) ring_emit_store<true>(a, c, em, eg);  // (its reads went out before k step 0)
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
                     v4i_t hi, lo;
                     hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
@@ -636,8 +659,9 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             }
         } else {
             if (STAGGER) asm volatile("s_barrier" ::: "memory");  // no tile this round (odd tile count): the mid-tile barrier alone
-            if (emit_now) ring_emit_store<true>(a, c, em, eg);
         }
+        }
+        if (store_pending) ring_emit_store<true>(a, c, em, eg);  // (no tile of its own this round)
         slot = (slot + 1 == R) ? 0 : slot + 1;
     }
     if (DEFER_ADDS && held_t >= 0) scatter(held_t, held1, held2);
@@ -654,7 +678,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
         const int k_last = (c.cnt + 62) >> 6;
         // the groups the loop has not emitted: PAIR emitted group k in round 2k + RG_EMIT_LAG_PAIR
         const int own = c.rounds - c.tshift;  // rounds in this lane's own count
-        const int k_next = PAIR ? (own > RG_EMIT_LAG_PAIR ? ((own - 1 - RG_EMIT_LAG_PAIR) >> 1) + 1 : 0) : max(c.rounds - RG_EMIT_LAG, 0);
+        const int k_next = PAIR1 ? (own > RG_EMIT_LAG_PAIR ? ((own - 1 - RG_EMIT_LAG_PAIR) >> 1) + 1 : 0) : max(own - RG_EMIT_LAG, 0);
         if (!PAIR || c.tshift < RG_PAIR_IDLE)  // (the idle half of a pair without a second lane emits nothing)
             for (int k = k_next; k <= k_last; ++k) ring_emit_group<ACC64>(a, c, em, k);
     }
@@ -685,7 +709,8 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     c.cnt = static_cast<int>(min(static_cast<long long>(a.range), a.n_out - c.i0));
     c.m0 = a.m_lo + c.i0;
     c.tiles = (c.cnt + 63 + 31) >> 5;  // data columns b in [m0-64, m0+cnt-2], rounded up to tiles of 32
-    c.rounds = PAIR ? c.tiles + a.pair_extra : (c.tiles + 1) >> 1;
+    c.rounds = G::PAIR1 ? c.tiles + a.pair_extra : ((c.tiles + 1) >> 1) + (PAIR ? a.pair_extra : 0);
+    c.extra = PAIR ? a.pair_extra : 0;
     c.tshift = PAIR ? a.pair_shift : 0;  // (RG_PAIR_IDLE: the idle half of a pair without a second lane -- barriers only)
     c.smem = smem;
     c.s_acc = reinterpret_cast<int *>(smem + R * G::TPR * SLOT);
@@ -731,6 +756,18 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
         // (waves go to SIMDs cyclically: issuers on SIMDs 0 and 1, lane A's emitter -- wave 2 -- on SIMD 2, lane B's -- wave
         // 7 -- on SIMD 3)
         constexpr int SA = SKIPK ? 2 : 0, SB = 0;  // (parity 0 = the pair's first lane)
+        if constexpr (G::PAIR2) {
+            // the single-lane kernel's roles: one issuing wave per SIMD (rt 0, 1 of parity 0 feed the round's first tile, rt 2, 3
+            // of parity 1 its second), one emitting wave per LANE (wave 2 = lane A's rt 2 on SIMD 2, wave 5 = lane B's rt 1 on
+            // SIMD 1: neither issues); no deferred adds (two tiles per round keep a SIMD's two waves out of step by themselves)
+            if ((c.rt >> 1) == c.cp) {
+                if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, true>(a, c, fq, std::integral_constant<int, SB>{});
+                else ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
+            } else if (c.cp == 0 && c.rt == 2) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq, std::integral_constant<int, SA>{});
+            else if (c.cp == 1 && c.rt == 1) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq, std::integral_constant<int, SB>{});
+            else if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq, std::integral_constant<int, SB>{});
+            else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
+        } else
         if (c.cp == 0 && c.rt < 2) ring_main<KS, DBG, ACC64, ROWS, U8, true, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
         else if (c.cp == 0 && c.rt == 2) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq, std::integral_constant<int, SA>{});
         else if (c.cp == 1 && c.rt == 3) ring_main<KS, DBG, ACC64, ROWS, U8, false, true, false, true>(a, c, fq, std::integral_constant<int, SB>{});
@@ -847,7 +884,8 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
         // tiles arrive 2 rounds per group of difference later; a pair without a second lane (afrag NULL) idles that half
         const RingLane &la = m.lane[li & ~1], &lb = m.lane[li | 1];
         const bool idle_b = lb.afrag == nullptr;
-        a.pair_extra = idle_b ? 0 : (la.col_shift - lb.col_shift) >> 5;
+        // (rounds the second lane works behind the first: two tiles per tap-row group of difference = one round of two tiles)
+        a.pair_extra = idle_b ? 0 : (la.col_shift - lb.col_shift) >> (RingGeo<KS, ROWS, U8, PAIR>::PAIR2 ? 6 : 5);
         a.col_shift = la.col_shift;
         if (li & 1) {
             a.pair_shift = idle_b ? RG_PAIR_IDLE : a.pair_extra;
