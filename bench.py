@@ -92,6 +92,30 @@ def parse_args():
     return ap.parse_args()
 
 
+class quiet_gc:
+    """Around a timed region: collect now, then no garbage collection until the region ends (as timeit does).  A generation-2
+    collection of this process takes 35-55 ms (profiles/r03_c1_gc_stall.txt: ONE of them inside 400 replays of 53 us each made
+    config 1's step read 0.19 ms instead of 0.053)."""
+
+    def __enter__(self):
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+
+    def __call__(self, fn):  # as a decorator: the whole sub-bench (reference counting still frees its arrays)
+        import functools
+
+        @functools.wraps(fn)
+        def inner(*a, **k):
+            with quiet_gc():
+                return fn(*a, **k)
+        return inner
+
+
 def rms_err(a, b) -> float:
     return float(np.sqrt(np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2)))
 
@@ -109,6 +133,7 @@ def padded_resident(host_i16: np.ndarray, n_total: int, slack: int):
     return buf
 
 
+@quiet_gc()
 def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     """BASELINE config 1: the reference's --benchmark capture (5 s @ 2.5 MS/s, NFM, +25 kHz) through the same runner."""
     import torch
@@ -156,6 +181,24 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     res = [runner.collect(t) for t in ts][-1]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # ... the same replays on TWO streams, round-robin by slot: a 50 MB capture's step is a chain of ten dependent kernels of a
+    # few microseconds each (80 us of GPU time per capture: latency, not work), so two captures' chains side by side fill each
+    # other's gaps -- independent captures, the same audio
+    runner2 = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch,
+                                    chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n, slots=8, graph_streams=2)
+    for t in [runner2.submit_captured(raw, enclosing=buf, lead_frames=0) for _ in range(warm)]:
+        runner2.collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts2, host_us2 = [], []
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        ts2.append(runner2.submit_captured(raw, enclosing=buf, lead_frames=0))
+        host_us2.append((time.perf_counter() - h0) * 1e6)
+    res2 = [runner2.collect(t) for t in ts2][-1]
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / steps
+    audio2 = res2["audio"].cpu().numpy()
     # ... and two captures per graph (a batch of captures in fixed buffers: one graph launch for both)
     pair = [(raw, buf, 0)] * 2
     for _ in range(warm // 2):
@@ -176,11 +219,16 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     return {
         "workload": "BASELINE config 1 (the reference's --benchmark capture): 5 s @ 2.5 MS/s int16 I/Q, 1 NFM channel, +25 kHz, "
                     f"bw 12.5 kHz, D={d}, {len(taps)} taps",
-        "value": round(n / dt / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
-        "step": f"captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured), {runner.SLOTS} captures in flight",
+        "value": round(n / dt2 / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt2 * 1e3, 4), "steps": steps,
+        "step": f"captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured), {runner2.SLOTS} captures in "
+                "flight, replays on two streams (independent captures side by side)",
+        "ms_per_step_one_stream": round(dt * 1e3, 4), "two_streams_audio_identical": bool(np.array_equal(audio, audio2)),
         "host_us_per_replay": {"mean": round(float(np.mean(host_us)), 1), "median": round(float(np.median(host_us)), 1),
                                "max": round(float(np.max(host_us)), 1),
                                "note": "host time inside submit_captured: wait for the capture `slots` back + hipGraphLaunch + event record"},
+        "host_us_per_replay_two_streams": {"mean": round(float(np.mean(host_us2)), 1), "median": round(float(np.median(host_us2)), 1),
+                                           "max": round(float(np.max(host_us2)), 1),
+                                           "by_quarter": [round(float(np.mean(q)), 1) for q in np.array_split(np.asarray(host_us2), 4)]},
         "ms_per_step_direct_launches": round(dt_eager * 1e3, 4), "replays_redone": dict(runner.redone),
         "ms_per_step_two_captures_per_graph": round(dt_batch * 1e3, 4), "two_per_graph_audio_identical": bool(np.array_equal(audio, audio_b)),
         "roofline": {"kernel": res["kernel"], "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
@@ -208,6 +256,7 @@ def _bank_traffic_ratio(tag_key: str):
     return None, f"no committed PMC profile for workload {tag_key!r}"
 
 
+@quiet_gc()
 def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 0.55) -> dict:
     """BASELINE config 3: 60 s @ 20 MS/s, five simultaneous targets (nfm/am/usb/lsb/nfm, bw 12.5k/10k/2.8k/2.8k/12.5k),
     AGC on (ResidentBankRunner).  Timed twice: at the precisions the product chooses (USB / LSB with the AGC on at "full":
@@ -298,6 +347,7 @@ def sub_bench_c3(steps: int = 20, warm: int = 6, cpu_seconds_of_signal: float = 
     }
 
 
+@quiet_gc()
 def sub_bench_c4_unit(steps: int = 60, warm: int = 60, cpu_seconds_of_signal: float = 0.5) -> dict:
     """BASELINE config 4's per-GPU unit: 60 s @ 20 MS/s int16, one NFM channel (D = 208, 12 801 taps, 13 k steps: the
     ring kernel without loader waves), through the same runner as the headline."""
@@ -350,6 +400,7 @@ def c5_targets(n_channels: int = 40) -> list:
     return [dict(freq_offset=-1.95e6 + 100e3 * k, demod_mode="nfm", bandwidth=12_500.0) for k in range(n_channels)]
 
 
+@quiet_gc()
 def sub_bench_c5_unit(steps: int = 20, warm: int = 6, uniq: float = 0.2) -> dict:
     """BASELINE config 5's per-GPU unit: five of the 40 NFM channels (first, second, the two around DC, last) of a
     50 MS/s capture, D = 521 (row-staged ring slots, 33 k steps in three chained launches of five lanes), on 1.2 G frames
@@ -407,6 +458,7 @@ def sub_bench_c5_unit(steps: int = 20, warm: int = 6, uniq: float = 0.2) -> dict
     }
 
 
+@quiet_gc()
 def file_to_wav_legs() -> list:
     """The literal metric -- file in, 48 kHz WAV out -- as the reference's --benchmark times it (benchmark.py:104-120): a
     PCM16 stereo WAV on disk -> ProcessingPipeline.run -> 48 kHz PCM16 WAV on disk, wall clock around run(), generation of
@@ -455,12 +507,15 @@ def file_to_wav_legs() -> list:
     return legs
 
 
+@quiet_gc()
 def host_resident_leg(runner, host_pinned, bufs, n_total: int, captures: int = 8) -> dict:
     """The step with the capture starting in pinned host memory: its upload (2.4 GB over PCIe) is inside the timed
     region, double-buffered against the previous capture's kernels."""
     import torch
 
-    up = torch.cuda.Stream()
+    from iq_to_audio_amd import _dev as D
+
+    up = D.side_stream("upload")
 
     def step(i):
         buf = bufs[i % 2]
@@ -545,13 +600,14 @@ def main_channel_axis(args, json_fd: int) -> None:
     warm = args.warmup if args.warmup != 100 else 2
     for _ in range(warm):
         job.step(stage)
-    DS.fence(None, sync=torch.cuda.synchronize)
-    t0 = time.perf_counter()
-    got = peak = None
-    for _ in range(steps):
-        got, peak = job.step(stage)
-    DS.fence(None, sync=torch.cuda.synchronize)
-    elapsed = DS.max_over_ranks(time.perf_counter() - t0)
+    with quiet_gc():
+        DS.fence(None, sync=torch.cuda.synchronize)
+        t0 = time.perf_counter()
+        got = peak = None
+        for _ in range(steps):
+            got, peak = job.step(stage)
+        DS.fence(None, sync=torch.cuda.synchronize)
+        elapsed = DS.max_over_ranks(time.perf_counter() - t0)
     ms_per_step = elapsed / steps * 1e3
     algo = 4.0 * n_total + len(targets) * 4.0 * 48_000.0 / fs * n_total
     out = {

@@ -29,6 +29,26 @@ class on_stream:
         return False
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def side_stream(role: str, index: int | None = None):
+    """The process-wide side stream for ``role`` on the current device ("aux", "egress", "tail", "graph0", ...), made on
+    first request and shared by every runner.  Why shared rather than one per runner: the HIP runtime multiplexes streams
+    onto a few hardware queues (``GPU_MAX_HW_QUEUES``, 4 by default), the least-used queue at a stream's first use -- a
+    runner whose side stream lands on the queue of its compute stream loses the overlap it wanted, and which queue a NEW
+    stream gets depends on every stream the process has used before (measured: config 4's unit 1.17 -> 1.33 ms, config 3
+    13.6 -> 15.3 ms per capture after an unrelated runner had taken four more streams).  A fixed,
+    small set of streams keeps the mapping the same for every runner of the process.  Sharing costs nothing in
+    correctness (stream order only adds dependencies) and runners are used one at a time."""
+    torch = torch_mod()
+    key = (torch.cuda.current_device() if index is None else int(index), role)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+    return s
+
+
 def current_raw_stream() -> int:
     """``hipStream_t`` of the current torch stream, as an integer."""
     torch = torch_mod()

@@ -54,13 +54,18 @@ class ResidentCaptureRunner:
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
                  fmt: str = "s16", iq_order: str = "iq", mix_sign_override: int | None = None, precision: str | None = None,
-                 precision_guard: float | None = None, slots: int | None = None):
+                 precision_guard: float | None = None, slots: int | None = None, graph_streams: int = 1):
         """``precision``: the channelizer precision every capture starts at (default: by demodulator,
         ``processing.base_precision``); ``precision_guard``: see ``processing.PRECISION_GUARD`` (0 = off).
         ``slots``: captures in flight (output buffers; default 2).  ``submit`` of capture i first waits for capture
         i - slots: with captures of tens of microseconds (BASELINE config 1 replayed as hipGraphs) two in flight make every
         step a host round trip -- event wait, wake-up, graph launch -- which some hosts take 0.2 ms for; eight in flight
-        keep ~0.6 ms of work queued and the step is the GPU's."""
+        keep ~0.6 ms of work queued and the step is the GPU's.
+        ``graph_streams``: streams the captured steps (``submit_captured``) are replayed on, round-robin by slot.  A small
+        capture's step is a chain of ten dependent kernels of a few microseconds each -- latency, not work (config 1: 80 us
+        of GPU time per capture for 50 MB) -- so the chains of two or three captures side by side fill the gaps of one
+        another.  Only for captures that are complete in device memory when ``submit_captured`` is called (the replay is not
+        ordered behind the caller's stream)."""
         torch = D.torch_mod()
         if slots is not None:
             if slots < 2:
@@ -83,14 +88,15 @@ class ResidentCaptureRunner:
         # (-6 % per capture at best while stretching the channelizer by 40 %: the small kernels take its CU slots).
         self.compute = torch.cuda.current_stream()
         self._compute_raw = int(self.compute.cuda_stream)
-        self.egress = torch.cuda.Stream()
-        self.aux = torch.cuda.Stream()
+        self.aux = D.side_stream("aux")  # (process-wide streams, first use in this order: _dev.side_stream says why)
+        self.egress = D.side_stream("egress")
         self._ring_done = None  # event behind the most recent channelizer launch (the aux stream starts from there)
         self.slots = [dict(z=D.empty(self.n_dec, "complex64"), audio=D.empty(self.n_dec, "float32"),
                            pcm_host=torch.empty(self.n48, dtype=torch.int16).pin_memory(), busy=None,
                            dem=ChannelDemod(demod_mode, self.fs_ch, deemph_us=deemph_us, agc_enabled=agc_enabled))
                       for _ in range(self.SLOTS)]
         self._next = 0
+        self._graph_streams = [D.side_stream(f"graph{i}") for i in range(int(graph_streams))] if int(graph_streams) > 1 else []
         self._egress_pending = None  # ticket whose D2H has not been queued yet (see _flush_egress)
         self.egress_workgroups = 8
 
@@ -149,7 +155,7 @@ class ResidentCaptureRunner:
             aux_done = torch.cuda.Event()
             aux_done.record(self.aux)
             if self.tail_beside_next:
-                self.__dict__.setdefault("_tail", torch.cuda.Stream()).wait_event(aux_done)
+                D.side_stream("tail").wait_event(aux_done)
             else:
                 self.compute.wait_event(aux_done)  # start-up outputs and decoder state are in place (long ago)
         if probe is not None:
@@ -158,7 +164,7 @@ class ResidentCaptureRunner:
         if resident and self.tail_beside_next:
             # demodulator + resampler on a stream of their own: they run beside the NEXT capture's channelizer (whose
             # workgroups leave them LDS and registers on every CU, see IQA_RING_ROUNDS_MAX) instead of in front of it
-            tail = self.__dict__.setdefault("_tail", torch.cuda.Stream())
+            tail = D.side_stream("tail")
             tail.wait_event(ring_done)
             with D.on_stream(tail, self.compute):
                 dem.process(slot["z"], self.starts, slot["audio"])
@@ -316,11 +322,17 @@ class ResidentCaptureRunner:
         else:
             self._next += 1
         entry["dem"].chunk_sumsq = entry["dem"].chunk_sumsq[-1:]  # (a replay re-runs the same demodulator call)
-        entry["graph"].replay()
         done = entry.get("done_event")  # (one event per graph: its slot's previous capture was collected above)
         if done is None:
             done = entry["done_event"] = torch.cuda.Event()
-        done.record()
+        if self._graph_streams:  # this slot's stream: the chains of consecutive captures run side by side
+            side = self._graph_streams[index % len(self._graph_streams)]
+            with torch.cuda.stream(side):
+                entry["graph"].replay()
+                done.record(side)
+        else:
+            entry["graph"].replay()
+            done.record()
         ticket = dict(chan=entry["chan"], dem=entry["dem"], pcm=entry["pcm"], done=done, tail_done=done, kernel=entry["kernel"],
                       slot=slot, egress_queued=True, resident=False, probe=None, graph_probe=entry["probe"],
                       sign=entry["sign"], precision=entry["precision"], raw=raw_dev, halo=halo)
@@ -502,7 +514,7 @@ class ResidentBankRunner:
             self.collect(slot["busy"])
         warm = raw_dev[: 2 * min(self.chunk, self.n_frames)] if self.fmt != "f32" else raw_dev[: min(self.chunk, self.n_frames)]
         main = torch.cuda.current_stream()
-        side = self.__dict__.setdefault("_tail_stream", torch.cuda.Stream()) if self.overlap_tails else None
+        side = D.side_stream("tail") if self.overlap_tails else None
         if side is not None:  # the capture is resident when submit is called: what depends on it alone may start now
             arrived = torch.cuda.Event()
             arrived.record(main)

@@ -525,6 +525,16 @@ def test_captured_step_replays_to_the_same_audio(A):
             assert r["sign"] == sign and np.array_equal(r["pcm_host"].numpy(), pcm) and torch.equal(r["audio"], audio), rep
     with pytest.raises(ValueError):
         runner.submit_captured_batch([(bufs[0], None, 0)] * (runner.SLOTS + 1))
+    # replays on two streams (graph_streams=2: consecutive captures' chains side by side), eight slots: the same PCM16 and
+    # audio, the buffer whose probe says -1 redone at collect as before
+    multi = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch, chunk=chunk, n_frames=n, slots=8,
+                                  graph_streams=2)
+    for rep in range(3):
+        tickets = [multi.submit_captured(bufs[k % 2]) for k in range(10)]
+        for k, t in enumerate(tickets):
+            sign, pcm, audio = want[k % 2]
+            r = multi.collect(t)
+            assert r["sign"] == sign and np.array_equal(r["pcm_host"].numpy(), pcm) and torch.equal(r["audio"], audio), (rep, k)
 
 
 # ---- dynamic range: a full-scale interferer beside an empty channel and beside a weak one ----------
