@@ -83,6 +83,16 @@
                                 // kernels of the previous capture's tail (the resampler wants 20), at 5 only 3
 #endif
 
+// 1: the kernels with loader waves over contiguous slots (<= IQA_RING_LOADERS_MAX_KS k steps: config 2) stage the capture as
+// BYTE PLANES: four loader waves fetch the tiles into registers (global_load_dwordx4, three rounds ahead), split every int16
+// into its high byte and its biased low byte ONCE and write the two planes into the slot; the multiplying waves read their
+// matrix operands straight out of the planes.  With raw tiles in LDS (0: LDS-DMA, the older form) each of a parity's four
+// multiplying waves split the same fragment again: 12 VALU instructions per k step and wave beside 3 MFMAs -- measured on the
+// sustained config-2 loop as 8.5 % of the kernel's time (diagnostic build "no byte splits", profiles/r03_sustained_ablation_splits.txt).
+#ifndef IQA_RING_SPLIT_STAGE
+#define IQA_RING_SPLIT_STAGE 1
+#endif
+
 #include <atomic>
 #include <mutex>
 #include <cmath>
@@ -169,13 +179,21 @@ struct RingGeo {
     static constexpr int NI_ROWS = (32 * UNITS_ROW + 63) / 64;
     static constexpr int SLOT = ROWS ? (32 * PITCH > 1024 * NI_ROWS ? 32 * PITCH : 1024 * NI_ROWS) : 1024 * NI;
     static constexpr bool LOADERS = !PAIR && (ROWS || KS <= IQA_RING_LOADERS_MAX_KS);  // two extra waves feed the ring and emit (needs <= 168 registers)
+    // byte-plane staging (IQA_RING_SPLIT_STAGE): a slot is [high bytes: 32 rows at PLANE_PITCH][biased low bytes: ditto], the
+    // same 1024 * NI bytes; the pitch is an odd number of 16-byte units (conflict-free ds_read_b128, lane = row).  FOUR
+    // loader waves, two per parity (wave `half` of a parity takes the tile's 1 KiB pieces 2 j + half, j < KS), SPLIT_F rounds
+    // of loads in flight in their registers (4 KS SPLIT_F of them), two slots per parity in LDS (one read, one written).
+    static constexpr bool SPLIT = LOADERS && !ROWS && !U8 && (IQA_RING_SPLIT_STAGE != 0);
+    static constexpr int PLANE_PITCH = 32 * KS + 16;
+    static constexpr int SPLIT_F = 3;
+    static constexpr int NLOADERS = SPLIT ? 4 : (LOADERS ? 2 : 0);
     static constexpr int NDMA = ROWS ? NI_ROWS : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
     static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
     static constexpr int R0 = FIT < RMAX ? FIT : RMAX;
     static constexpr int RCAP = PAIR ? IQA_RING_PAIR_ROUNDS : IQA_RING_ROUNDS_MAX;
-    static constexpr int R = R0 > RCAP ? RCAP : (R0 < 2 ? 2 : R0);  // rounds (of two tiles; PAIR: of one) the ring holds
-    static constexpr int THREADS = (RG_WAVES + (LOADERS ? 2 : 0)) * kWave;
+    static constexpr int R = SPLIT ? 2 : R0 > RCAP ? RCAP : (R0 < 2 ? 2 : R0);  // rounds (of two tiles; PAIR: of one) the ring holds
+    static constexpr int THREADS = (RG_WAVES + NLOADERS) * kWave;
     static constexpr int LDS_BYTES = R * TPR * SLOT + ACCS * RG_ACC_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "ring + window exceed LDS");
     static_assert((R - 2) * NDMA <= 63, "vmcnt is a 6-bit counter");
@@ -395,10 +413,114 @@ __device__ __forceinline__ void ring_loader(const MfmaArgs &a, const RingCtx &c)
         if ((k & 1) == cp) ring_emit_group<ACC64>(a2, c, em, k);
 }
 
+// A loader wave of the byte-plane kernels (RingGeo::SPLIT): parity cp, half `half`.  Round r: behind the barrier it waits
+// for ITS pieces of the tile of round r + 1 (requested SPLIT_F rounds ago), splits them and writes the planes of slot
+// (r + 1) % 2 -- the slot round r - 1 has just left --, requests the tile of round r + 1 + SPLIT_F into the registers that
+// became free, and (half 0) emits like ring_loader.  Plain loads: the compiler counts vmcnt itself, the emission's store
+// included.  Pieces beyond the tile's last unit (a tile is D / 8 pieces, a wave pair fetches 2 KS) re-fetch the last unit
+// and are not written.
+struct __attribute__((packed, aligned(4))) ring_raw16 {  // 16 bytes of the capture: dword-aligned (the stream starts at frame row*D + 1)
+    int x, y, z, w;
+};
+
+template <int KS, int DBG, bool ACC64>
+__device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingCtx &c, int half)
+{
+    using G = RingGeo<KS, false, false>;
+    constexpr int SLOT = G::SLOT, PP = G::PLANE_PITCH, F = G::SPLIT_F;
+    constexpr bool STREAM = !(DBG & 16);
+    const int cp = c.cp;
+    const int units = 32 * c.row_units;  // 16-byte units of a tile
+    int doff[KS];                        // where this lane's piece j goes inside a slot's high plane (8 bytes); -1: nowhere
+    int soff[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        const int q = 64 * (2 * j + half) + c.lane;
+        const int row = q / c.row_units, u = q - row * c.row_units;
+        doff[j] = q < units ? row * PP + 8 * u : -1;
+        soff[j] = 16 * min(q, units - 1);
+    }
+    int4 buf[F][KS];
+    auto request = [&](int round, auto set) {
+        constexpr int S = decltype(set)::value;
+        const char *src = c.stream0 + static_cast<long long>(min(2 * round + cp, c.tiles - 1)) * c.tile_bytes;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const ring_raw16 t = *reinterpret_cast<const ring_raw16 *>(src + soff[j]);
+            buf[S][j] = make_int4(t.x, t.y, t.z, t.w);
+        }
+    };
+    auto stage = [&](int slot, auto set) {
+        constexpr int S = decltype(set)::value;
+        char *hi0 = c.smem + (slot * 2 + cp) * SLOT;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int4 d = buf[S][j];
+            int2 hi, lo;
+            hi.x = __builtin_amdgcn_perm(d.y, d.x, 0x07050301);
+            hi.y = __builtin_amdgcn_perm(d.w, d.z, 0x07050301);
+            lo.x = __builtin_amdgcn_perm(d.y, d.x, 0x06040200) ^ 0x80808080;
+            lo.y = __builtin_amdgcn_perm(d.w, d.z, 0x06040200) ^ 0x80808080;
+            if (doff[j] >= 0) {
+                *reinterpret_cast<int2 *>(hi0 + doff[j]) = hi;
+                *reinterpret_cast<int2 *>(hi0 + 32 * PP + doff[j]) = lo;
+            }
+        }
+    };
+    // prologue: the tile of round 0 into slot 0 (before the block's first barrier), rounds 1 .. F requested
+    if (STREAM) {
+        request(0, std::integral_constant<int, 0>{});
+        stage(0, std::integral_constant<int, 0>{});
+        request(1, std::integral_constant<int, 1 % F>{});
+        request(2, std::integral_constant<int, 2 % F>{});
+        request(3, std::integral_constant<int, 3 % F>{});
+    }
+    static_assert(F == 3, "the prologue and the unrolled loop below are written for three rounds in flight");
+    RingEmit em{1.0, 0.0};
+    double st_re = a.rot64_re * a.rot64_re - a.rot64_im * a.rot64_im, st_im = 2.0 * a.rot64_re * a.rot64_im;  // 128 outputs
+    if (half == 0 && a.finalize && a.rotate) {
+        const unsigned long long m = static_cast<unsigned long long>(c.m0 + (64 * cp + 1 + c.lane - MF_Q));  // group cp
+        const unsigned long long ph = a.rot_base + m * a.rot_step;
+        sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &em.ws, &em.wc);
+    }
+    MfmaArgs a2 = a;  // ring_emit_group advances the rotation by (rot64_re, rot64_im): this wave owns every other group
+    a2.rot64_re = st_re;
+    a2.rot64_im = st_im;
+    auto round_body = [&](int r, auto set) {
+        // (the planes of round r were written before this barrier: lgkmcnt(0) in front of it)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (STREAM && r + 1 < c.rounds) stage((r + 1) & 1, set);
+        if (STREAM) request(r + 1 + F, set);  // (beyond the last tile: the last tile again, never staged)
+        if (half == 0 && r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) {
+            asm volatile("" ::: "memory");
+            ring_emit_group<ACC64>(a2, c, em, r - RG_EMIT_LAG);  // (see ring_loader for why these sums are final)
+            asm volatile("" ::: "memory");
+        }
+    };
+    // round r stages the tile of round r + 1, which sits in register set (r + 1) % F
+    int r = 0;
+    for (; r + 3 <= c.rounds; r += 3) {
+        round_body(r, std::integral_constant<int, 1>{});
+        round_body(r + 1, std::integral_constant<int, 2>{});
+        round_body(r + 2, std::integral_constant<int, 0>{});
+    }
+    if (r < c.rounds) {
+        round_body(r, std::integral_constant<int, 1>{});
+        if (r + 1 < c.rounds) round_body(r + 1, std::integral_constant<int, 2>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (half == 0) {
+        const int k_last = (c.cnt + 62) >> 6;
+        for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k)
+            if ((k & 1) == cp) ring_emit_group<ACC64>(a2, c, em, k);
+    }
+}
+
 // The main loop of a multiplying wave.  ISSUER (kernels without loader waves): this wave also feeds the ring
 // (chunks 2i + (rt & 1) of its parity's slot).  EMIT (ditto): this wave also converts, rotates and stores the 64
 // outputs that became complete two rounds ago.
-// DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work.
+// DBG bits (diagnostic instantiations only): 1 = no scatter, 16 = no data stream, 32 = no matrix work, 4 = every second
+// multiplying wave without fragment reads and byte splits, 8 = no byte splits.
 // SKIP: what this wave does with the q2*hi product (the third matrix instruction of a k step): 0 = always computes it;
 // 2 = never (its lane's low tap byte is zero throughout: the first lane of a "fine" / "full" tap-row group); 1 = asks the
 // lane's flag at run time (both bodies in the code: ~30 registers more, so only the kernels of such launches carry it).
@@ -603,6 +725,39 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                         if (IQA_RING_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
+                if constexpr (G::SPLIT) {
+                    // byte planes: the operands as they lie in the slot (high bytes at la, biased low bytes 32 rows further)
+                    v4i_t hh[KS], ll[KS];
+#pragma unroll
+                    for (int ks = 0; ks < PD; ++ks) {
+                        hh[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * ks);
+                        ll[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * G::PLANE_PITCH + 32 * ks);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const v4i_t hi = hh[ks], lo = ll[ks];
+                        if (ks + PD < KS) {
+                            hh[ks + PD] = *reinterpret_cast<const v4i_t *>(la + 32 * (ks + PD));
+                            ll[ks + PD] = *reinterpret_cast<const v4i_t *>(la + 32 * G::PLANE_PITCH + 32 * (ks + PD));
+                        }
+                        if (DBG & 32) {
+                            asm volatile("" ::"v"(hi), "v"(lo));
+                        } else {
+                            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], hi, ks ? acc1 : zero16, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], lo, ks ? acc2 : zero16, 0, 0, 0);
+                            if constexpr (!SKIP_LOW) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
+                        }
+                    }
+                } else if ((DBG & 4) && (rt & 1)) {
+                    // diagnostic: every second wave multiplies register constants -- half the fragment reads and byte splits of
+                    // a workgroup, all of its matrix work (what a wave holding 64 tap rows per data fragment would save)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], fq[ks][1], ks ? acc1 : zero16, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], fq[ks][0], ks ? acc2 : zero16, 0, 0, 0);
+                        if constexpr (!SKIP_LOW) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], fq[ks][1], acc2, 0, 0, 0);
+                    }
+                } else {
                 v4i_t dd[KS][2];
 #pragma unroll
                 for (int ks = 0; ks < PD; ++ks) {
@@ -616,6 +771,10 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     if (EMIT && ks == KS - 3 && store_here) ring_emit_store<true>(a, c, em, eg);  // (its reads went out before k step 0)
                     const v4i_t d0 = dd[ks][0], d1 = dd[ks][1];
                     v4i_t hi, lo;
+                    if (DBG & 8) {  // diagnostic: no byte split
+                        hi = d0;
+                        lo = d1;
+                    } else {
                     hi.x = __builtin_amdgcn_perm(d0.y, d0.x, 0x07050301);
                     hi.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x07050301);
                     hi.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x07050301);
@@ -624,6 +783,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                     lo.y = __builtin_amdgcn_perm(d0.w, d0.z, 0x06040200) ^ 0x80808080;
                     lo.z = __builtin_amdgcn_perm(d1.y, d1.x, 0x06040200) ^ 0x80808080;
                     lo.w = __builtin_amdgcn_perm(d1.w, d1.z, 0x06040200) ^ 0x80808080;
+                    }
                     if (ks + PD < KS) {
                         dd[ks + PD][0] = *reinterpret_cast<const v4i_t *>(la + 64 * (ks + PD));
                         dd[ks + PD][1] = *reinterpret_cast<const v4i_t *>(la + 64 * (ks + PD) + 16);
@@ -636,6 +796,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                         if constexpr (!SKIP_LOW) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][1], hi, acc2, 0, 0, 0);
                     }
                     if (IQA_RING_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 }
                 if (DBG & 32) acc1 = acc2 = zero16;
@@ -725,14 +886,15 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
                          (ROWS ? G::KBYTES * a.k_first : 0);
     c.row_units = static_cast<int>(row_bytes >> 4);
     c.pitch_units = G::PADDED ? (c.row_units | 1) : c.row_units;  // odd: conflict-free fragment reads (see RingGeo)
-    c.lane_off = c.col * (ROWS ? G::PITCH : 16 * c.pitch_units) + (G::KBYTES / 2) * c.h;
+    c.lane_off = G::SPLIT ? c.col * G::PLANE_PITCH + 16 * c.h : c.col * (ROWS ? G::PITCH : 16 * c.pitch_units) + (G::KBYTES / 2) * c.h;
 
     if constexpr (LOADERS) {
         if (wave >= RG_WAVES) {
-            c.cp = wave - RG_WAVES;
+            c.cp = (wave - RG_WAVES) & 1;
             c.stream0 = stream;
             __syncthreads();
-            ring_loader<KS, DBG, ACC64, ROWS, U8>(a, c);
+            if constexpr (G::SPLIT) ring_loader_split<KS, DBG, ACC64>(a, c, (wave - RG_WAVES) >> 1);
+            else ring_loader<KS, DBG, ACC64, ROWS, U8>(a, c);
             return;
         }
     }
@@ -1118,7 +1280,7 @@ size_t mfma_ring_lds_bytes(int ksteps, bool rows, bool u8)
 // debug bit 7 (128) selects the 32-bit sums (needs fragments from dsp_plan.plan_mfma(acc32=True))
 int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream, bool rows, bool u8)
 {
-    const int dbg = a.debug & (1 | 2 | 16 | 32);
+    const int dbg = a.debug & (1 | 2 | 4 | 8 | 16 | 32);
     const bool acc64 = !(a.debug & 128);
     if (u8) {
         switch (a.ksteps) {
@@ -1149,6 +1311,10 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
             case 17: return ring_launch_one<7, 17, false>(a, blocks, lds, stream);
             case 32: return ring_launch_one<7, 32, false>(a, blocks, lds, stream);
             case 33: return ring_launch_one<7, 33, false>(a, blocks, lds, stream);
+            case 4: return ring_launch_one<7, 4, false>(a, blocks, lds, stream);
+            case 8: return ring_launch_one<7, 8, false>(a, blocks, lds, stream);
+            case 5: return ring_launch_one<7, 5, false>(a, blocks, lds, stream);
+            case 13: return ring_launch_one<7, 13, false>(a, blocks, lds, stream);
             default: break;
         }
     }
@@ -1159,6 +1325,8 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
             case 17: return ring_launch_one<13, 17, false>(a, blocks, lds, stream);
             case 32: return ring_launch_one<13, 32, false>(a, blocks, lds, stream);
             case 33: return ring_launch_one<13, 33, false>(a, blocks, lds, stream);
+            case 4: return ring_launch_one<13, 4, false>(a, blocks, lds, stream);
+            case 8: return ring_launch_one<13, 8, false>(a, blocks, lds, stream);
             case 2: return ring_launch_one<13, 2, false>(a, blocks, lds, stream);    // per-wave barrier-wait / work cycles
             case 18: return ring_launch_one<13, 18, false>(a, blocks, lds, stream);  // the same without the DMA stream
             default: break;

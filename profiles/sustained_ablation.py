@@ -1,6 +1,7 @@
 """Ring-kernel ablations in the SUSTAINED (power-limited) regime: every variant runs N back-to-back launches and the
 median of the second half is reported, together with rocm-smi's clock/power at that point.  Debug bits (KS = 7 or, with FS=20e6, 13; int32
-sums): 1 = no scatter, 16 = no DMA, 32 = no matrix work.  Usage: python profiles/sustained_ablation.py [N]"""
+sums): 1 = no scatter, 16 = no DMA, 32 = no matrix work, 4 = every second multiplying wave without fragment reads and byte
+splits, 8 = no byte splits.  Usage: python profiles/sustained_ablation.py [N]"""
 import re, subprocess, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -33,7 +34,8 @@ def smi():
     except Exception as e:
         return f"rocm-smi failed: {e}"
 
-names = {0: "everything", 1: "no scatter", 16: "no DMA", 32: "no matrix work", 33: "DMA + LDS reads only", 17: "matrix work + LDS reads only"}
+names = {0: "everything", 1: "no scatter", 16: "no DMA", 32: "no matrix work", 33: "DMA + LDS reads only", 17: "matrix work + LDS reads only",
+         4: "half the fragment reads + splits", 8: "no byte splits", 5: "half reads + splits, no scatter", 13: "half reads, no splits, no scatter"}
 DBGS = [int(v) for v in os.environ.get("DBGS", "0,1,16,32,33,17").split(",")]
 for rnd in range(int(os.environ.get("ROUNDS", "2"))):
     for dbg in DBGS:
