@@ -49,7 +49,12 @@ class ResidentCaptureRunner:
 
     #: submit(resident=True): demodulator + resampler of capture i on their own stream, beside the channelizer of capture i + 1
     tail_beside_next = bool(int(__import__("os").environ.get("IQA_TAIL_STREAM", "0")))
-    SLOTS = 3 if tail_beside_next else 2
+    # Output buffers in flight.  Three: the PCM16 copy of capture i (a handful of workgroups on the egress stream) is meant to
+    # run beside the channelizer of capture i + 1, but a channelizer whose workgroups fill every SIMD's register file (twelve
+    # waves of 160+ registers: the byte-plane kernels at 12-13 k steps) leaves it no wave slot -- the copy then completes when
+    # that channelizer ends, and with two buffers the host could not queue capture i + 2 before: a bubble of one host
+    # submission per capture (config 4's unit: 1.35 ms per capture for a 0.95 ms kernel).
+    SLOTS = 3
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,

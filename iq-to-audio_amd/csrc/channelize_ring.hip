@@ -47,12 +47,13 @@
 // keeps the pipe 96 % busy: probe/kstep_probe.hip).  MEASURED and left off: 9.48 against 9.15 ms on the five-target launch,
 // 1.057 against 1.055 ms on one channel at D = 208 -- tile boundaries are not what holds this kernel back (DESIGN.md
 // section 6).  Build-time knob for A/B measurements only.
-// Loader waves (two extra waves that feed the ring and emit) up to this many k steps.  13 fits the registers (157) and is
-// 4 % faster on the five-target launch (8.9 against 9.1-9.6 ms) but loosens the lock-step of a range's lanes: the launch's
-// L2 misses rise from 1.003x the capture to 1.1-1.4x, varying from launch to launch (FETCH_SIZE: 5.4-7.0 GB against a
-// steady 4.81 GB).  The shared-ingest design is about that number, so the multiplying waves keep issuing at 9..16 k steps.
+// Loader waves (extra waves that feed the ring and emit) up to this many k steps; 14..16 k steps need more registers than
+// twelve waves leave each other (168), there the multiplying waves issue LDS-DMAs themselves.  With LDS-DMA staging
+// (IQA_RING_SPLIT_STAGE=0) round 2 measured loaders at 13 k steps as 4 % faster on a five-target launch of single lanes but
+// with L2 misses of 1.1-1.4x the capture instead of 1.003x (the lanes of a range lose their lock-step); banks at 9..16 k
+// steps run as lane PAIRS (no loader waves, paced), so this concerns the single-lane kernels.
 #ifndef IQA_RING_LOADERS_MAX_KS
-#define IQA_RING_LOADERS_MAX_KS 8
+#define IQA_RING_LOADERS_MAX_KS 13
 #endif
 // A/B knobs for the waves' interplay on a SIMD (diagnostic builds): IQA_RING_DEFER 0 = parity-1 waves scatter their tile
 // right behind it like parity 0; IQA_RING_PRIO 1 = parity-1 waves run at raised priority (s_setprio 1), 2 = parity-0 waves.
@@ -91,6 +92,9 @@
 // sustained config-2 loop as 8.5 % of the kernel's time (diagnostic build "no byte splits", profiles/r03_sustained_ablation_splits.txt).
 #ifndef IQA_RING_SPLIT_STAGE
 #define IQA_RING_SPLIT_STAGE 1
+#endif
+#ifndef IQA_RING_SPLIT_F3_MAX_KS
+#define IQA_RING_SPLIT_F3_MAX_KS 8  // three rounds of loads in flight up to this many k steps, two beyond (registers)
 #endif
 
 #include <atomic>
@@ -177,16 +181,17 @@ struct RingGeo {
     // instead of one per row with 4 KS of 64 lanes active (2 k steps: 5 instead of 32)
     static constexpr int UNITS_ROW = PITCH / 16;
     static constexpr int NI_ROWS = (32 * UNITS_ROW + 63) / 64;
-    static constexpr int SLOT = ROWS ? (32 * PITCH > 1024 * NI_ROWS ? 32 * PITCH : 1024 * NI_ROWS) : 1024 * NI;
+    static constexpr int SLOT_RAW = ROWS ? (32 * PITCH > 1024 * NI_ROWS ? 32 * PITCH : 1024 * NI_ROWS) : 1024 * NI;
     static constexpr bool LOADERS = !PAIR && (ROWS || KS <= IQA_RING_LOADERS_MAX_KS);  // two extra waves feed the ring and emit (needs <= 168 registers)
     // byte-plane staging (IQA_RING_SPLIT_STAGE): a slot is [high bytes: 32 rows at PLANE_PITCH][biased low bytes: ditto], the
     // same 1024 * NI bytes; the pitch is an odd number of 16-byte units (conflict-free ds_read_b128, lane = row).  FOUR
     // loader waves, two per parity (wave `half` of a parity takes the tile's 1 KiB pieces 2 j + half, j < KS), SPLIT_F rounds
     // of loads in flight in their registers (4 KS SPLIT_F of them), two slots per parity in LDS (one read, one written).
-    static constexpr bool SPLIT = LOADERS && !ROWS && !U8 && (IQA_RING_SPLIT_STAGE != 0);
+    static constexpr bool SPLIT = LOADERS && !U8 && (IQA_RING_SPLIT_STAGE != 0);
     static constexpr int PLANE_PITCH = 32 * KS + 16;
-    static constexpr int SPLIT_F = 3;
+    static constexpr int SPLIT_F = KS <= IQA_RING_SPLIT_F3_MAX_KS ? 3 : 2;  // (a loader wave has 168 registers: 4 KS SPLIT_F of data, 2 KS of offsets, the emission)
     static constexpr int NLOADERS = SPLIT ? 4 : (LOADERS ? 2 : 0);
+    static constexpr int SLOT = SPLIT ? 64 * PLANE_PITCH : SLOT_RAW;
     static constexpr int NDMA = ROWS ? NI_ROWS : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
     static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
     static constexpr int RMAX = 63 / NDMA + 2;  // (R - 2) * NDMA must fit the 6-bit vmcnt
@@ -423,30 +428,61 @@ struct __attribute__((packed, aligned(4))) ring_raw16 {  // 16 bytes of the capt
     int x, y, z, w;
 };
 
-template <int KS, int DBG, bool ACC64>
-__device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingCtx &c, int half)
+template <int KS, int DBG, bool ACC64, bool ROWS, int HALF>
+__device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingCtx &c)
 {
-    using G = RingGeo<KS, false, false>;
+    constexpr int half = HALF;
+    // pieces of a tile this wave takes: every second one, or -- from 12 k steps on, where 8 KS registers of data in flight
+    // and the emission's float64 state do not fit one wave -- the emitting wave (half 0) the first KS - 2, the other the rest
+    constexpr bool UNEVEN = KS >= 12;
+    constexpr int P0 = UNEVEN ? KS - 2 : KS;
+    constexpr int NP = UNEVEN ? (HALF ? 2 * KS - P0 : P0) : KS;
+    auto piece = [](int j) { return UNEVEN ? (HALF ? P0 + j : j) : 2 * j + HALF; };
+    using G = RingGeo<KS, ROWS, false>;
     constexpr int SLOT = G::SLOT, PP = G::PLANE_PITCH, F = G::SPLIT_F;
     constexpr bool STREAM = !(DBG & 16);
     const int cp = c.cp;
-    const int units = 32 * c.row_units;  // 16-byte units of a tile
-    int doff[KS];                        // where this lane's piece j goes inside a slot's high plane (8 bytes); -1: nowhere
-    int soff[KS];
+    // 16-byte units of a data row that are staged: the whole row (contiguous slots: rows follow one another in the capture)
+    // or this pass's 4 KS units of it (row-staged slots); a tile is 32 rows of them, unit q = unit q % upr of row q / upr
+    const int upr = ROWS ? 4 * KS : c.row_units;
+    const int row_bytes = static_cast<int>(c.tile_bytes >> 5);
+    // piece j of this wave is unit q = 64 piece(j) + lane = unit u of row `row`.  Up to 8 k steps its source and
+    // destination offsets sit in two tables; longer rows keep 16 bits (row, u) per piece and spend a few
+    // VALU instructions on them -- 2 KS registers the loader does not have beside 8 KS of data in flight.  (Walking (row, u) from
+    // piece to piece instead, with its lane-divergent carry loop, made the loaders the slowest waves of the workgroup:
+    // 1.55 against 1.09 ms at 13 k steps.)
+    constexpr bool TABLE = KS <= 8;
+    int doff[TABLE ? NP : 1], soff[TABLE ? NP : 1];
+    unsigned rowu[TABLE ? 1 : (NP + 1) / 2];  // two pieces per word: u (6 bits: a row holds <= 64 units), row (5), "not written" (1)
+    if constexpr (!TABLE) {
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-        const int q = 64 * (2 * j + half) + c.lane;
-        const int row = q / c.row_units, u = q - row * c.row_units;
-        doff[j] = q < units ? row * PP + 8 * u : -1;
-        soff[j] = 16 * min(q, units - 1);
+        for (int j = 0; j < (NP + 1) / 2; ++j) rowu[j] = 0;
     }
-    int4 buf[F][KS];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = 64 * piece(j) + c.lane;
+        const int row = q / upr, u = q - row * upr;
+        if constexpr (TABLE) {
+            doff[j] = row < 32 ? row * PP + 8 * u : -1;
+            soff[j] = row < 32 ? row * row_bytes + 16 * u : 31 * row_bytes + 16 * (upr - 1);
+        } else {
+            const unsigned f = row < 32 ? static_cast<unsigned>((row << 6) | u) : static_cast<unsigned>((31 << 6) | (upr - 1) | (1 << 11));
+            rowu[j >> 1] |= f << (16 * (j & 1));
+        }
+    }
+    int4 buf[F][NP];
     auto request = [&](int round, auto set) {
         constexpr int S = decltype(set)::value;
         const char *src = c.stream0 + static_cast<long long>(min(2 * round + cp, c.tiles - 1)) * c.tile_bytes;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const ring_raw16 t = *reinterpret_cast<const ring_raw16 *>(src + soff[j]);
+        for (int j = 0; j < NP; ++j) {
+            int so;
+            if constexpr (TABLE) so = soff[j];
+            else {
+                const unsigned f = rowu[j >> 1] >> (16 * (j & 1));
+                so = static_cast<int>((f >> 6) & 31u) * row_bytes + 16 * static_cast<int>(f & 63u);
+            }
+            const ring_raw16 t = *reinterpret_cast<const ring_raw16 *>(src + so);
             buf[S][j] = make_int4(t.x, t.y, t.z, t.w);
         }
     };
@@ -454,16 +490,22 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
         constexpr int S = decltype(set)::value;
         char *hi0 = c.smem + (slot * 2 + cp) * SLOT;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int4 d = buf[S][j];
             int2 hi, lo;
             hi.x = __builtin_amdgcn_perm(d.y, d.x, 0x07050301);
             hi.y = __builtin_amdgcn_perm(d.w, d.z, 0x07050301);
             lo.x = __builtin_amdgcn_perm(d.y, d.x, 0x06040200) ^ 0x80808080;
             lo.y = __builtin_amdgcn_perm(d.w, d.z, 0x06040200) ^ 0x80808080;
-            if (doff[j] >= 0) {
-                *reinterpret_cast<int2 *>(hi0 + doff[j]) = hi;
-                *reinterpret_cast<int2 *>(hi0 + 32 * PP + doff[j]) = lo;
+            int dq;
+            if constexpr (TABLE) dq = doff[j];
+            else {
+                const unsigned f = rowu[j >> 1] >> (16 * (j & 1));
+                dq = (f & 2048u) ? -1 : static_cast<int>((f >> 6) & 31u) * PP + 8 * static_cast<int>(f & 63u);
+            }
+            if (dq >= 0) {
+                *reinterpret_cast<int2 *>(hi0 + dq) = hi;
+                *reinterpret_cast<int2 *>(hi0 + 32 * PP + dq) = lo;
             }
         }
     };
@@ -473,9 +515,9 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
         stage(0, std::integral_constant<int, 0>{});
         request(1, std::integral_constant<int, 1 % F>{});
         request(2, std::integral_constant<int, 2 % F>{});
-        request(3, std::integral_constant<int, 3 % F>{});
+        if constexpr (F == 3) request(3, std::integral_constant<int, 0>{});
     }
-    static_assert(F == 3, "the prologue and the unrolled loop below are written for three rounds in flight");
+    static_assert(F == 2 || F == 3, "the prologue and the unrolled loop below are written for two or three rounds in flight");
     RingEmit em{1.0, 0.0};
     double st_re = a.rot64_re * a.rot64_re - a.rot64_im * a.rot64_im, st_im = 2.0 * a.rot64_re * a.rot64_im;  // 128 outputs
     if (half == 0 && a.finalize && a.rotate) {
@@ -486,27 +528,53 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
     MfmaArgs a2 = a;  // ring_emit_group advances the rotation by (rot64_re, rot64_im): this wave owns every other group
     a2.rot64_re = st_re;
     a2.rot64_im = st_im;
+    // The partial sums of the earlier passes (a long row's k-step ranges) are requested ONE ROUND AHEAD of their emission and
+    // in front of that round's tile request: loads return in order, so waiting for a load issued behind the tile requests
+    // -- where the emission uses it -- would wait for every tile in flight: the prefetch drained every other round.
+    // (Up to 11 k steps; at 12 and 13 the four registers are not there, and the partial sums are loaded where they are used.)
+    constexpr bool PR_AHEAD = KS <= 11;
+    double2 pr_next = make_double2(0.0, 0.0);
     auto round_body = [&](int r, auto set) {
         // (the planes of round r were written before this barrier: lgkmcnt(0) in front of it)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (STREAM && r + 1 < c.rounds) stage((r + 1) & 1, set);
+        const double2 pr_now = pr_next;
+        if (PR_AHEAD && half == 0 && a.partial_in != nullptr && r + 1 >= RG_EMIT_LAG && ((r + 1 - RG_EMIT_LAG) & 1) == cp) {
+            const int i = 64 * (r + 1 - RG_EMIT_LAG) + 1 + c.lane - MF_Q;
+            pr_next = (i >= 0 && i < c.cnt) ? a.partial_in[c.i0 + i] : make_double2(0.0, 0.0);
+        }
         if (STREAM) request(r + 1 + F, set);  // (beyond the last tile: the last tile again, never staged)
         if (half == 0 && r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) {
             asm volatile("" ::: "memory");
-            ring_emit_group<ACC64>(a2, c, em, r - RG_EMIT_LAG);  // (see ring_loader for why these sums are final)
+            if constexpr (PR_AHEAD) {
+                RingEmitRegs g;  // (see ring_loader for why these sums are final)
+                ring_emit_load<ACC64, false>(a2, c, r - RG_EMIT_LAG, g);
+                g.pr = pr_now;
+                ring_emit_store<true>(a2, c, em, g);
+            } else {
+                ring_emit_group<ACC64>(a2, c, em, r - RG_EMIT_LAG);
+            }
             asm volatile("" ::: "memory");
         }
     };
     // round r stages the tile of round r + 1, which sits in register set (r + 1) % F
     int r = 0;
-    for (; r + 3 <= c.rounds; r += 3) {
-        round_body(r, std::integral_constant<int, 1>{});
-        round_body(r + 1, std::integral_constant<int, 2>{});
-        round_body(r + 2, std::integral_constant<int, 0>{});
-    }
-    if (r < c.rounds) {
-        round_body(r, std::integral_constant<int, 1>{});
-        if (r + 1 < c.rounds) round_body(r + 1, std::integral_constant<int, 2>{});
+    if constexpr (F == 3) {
+        for (; r + 3 <= c.rounds; r += 3) {
+            round_body(r, std::integral_constant<int, 1>{});
+            round_body(r + 1, std::integral_constant<int, 2>{});
+            round_body(r + 2, std::integral_constant<int, 0>{});
+        }
+        if (r < c.rounds) {
+            round_body(r, std::integral_constant<int, 1>{});
+            if (r + 1 < c.rounds) round_body(r + 1, std::integral_constant<int, 2>{});
+        }
+    } else {
+        for (; r + 2 <= c.rounds; r += 2) {
+            round_body(r, std::integral_constant<int, 1>{});
+            round_body(r + 1, std::integral_constant<int, 0>{});
+        }
+        if (r < c.rounds) round_body(r, std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (half == 0) {
@@ -893,7 +961,10 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
             c.cp = (wave - RG_WAVES) & 1;
             c.stream0 = stream;
             __syncthreads();
-            if constexpr (G::SPLIT) ring_loader_split<KS, DBG, ACC64>(a, c, (wave - RG_WAVES) >> 1);
+            if constexpr (G::SPLIT) {
+                if ((wave - RG_WAVES) >> 1) ring_loader_split<KS, DBG, ACC64, ROWS, 1>(a, c);
+                else ring_loader_split<KS, DBG, ACC64, ROWS, 0>(a, c);
+            }
             else ring_loader<KS, DBG, ACC64, ROWS, U8>(a, c);
             return;
         }
@@ -1165,7 +1236,7 @@ static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds
     return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[0]);
 }
 
-constexpr int RG_PAIR_MIN_KS = IQA_RING_LOADERS_MAX_KS + 1;  // lane pairs where the single-lane kernel runs without loader waves
+constexpr int RG_PAIR_MIN_KS = 9;  // lane pairs from 9 k steps on (below, a range's single-lane workgroups share the capture through L2 by themselves)
 
 template <int KS>
 static int ring_launch_pairs(const RingMultiArgs &m, unsigned blocks, hipStream_t stream, bool acc64, bool skipk)
