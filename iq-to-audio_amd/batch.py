@@ -451,6 +451,19 @@ class ResidentBankRunner:
     SLOTS = 3  # output buffers in flight: with the tails of capture i finishing somewhere inside the pass of capture i + 1, a
                # third slot lets the host queue capture i + 2 without waiting for them
     overlap_tails = True  # the per-target chains of capture i beside the channelizer pass of capture i + 1
+    # Where a capture's float32 edge launches and combine launches go: False = the caller's stream, between the passes (they
+    # are short); True = the tails' stream, "own" = a third stream.  On a side stream they kept the caller's stream free for
+    # the passes while the previous capture's chains found room BESIDE a pass; behind a pass of twelve waves x 160+
+    # registers per workgroup the chains finish late, and everything queued behind them -- these launches, and with them the
+    # next pass -- waited: config 3 measured 13.6 ms per capture (= everything on one stream) against 13.2-13.3 with them on
+    # the caller's stream (profiles/r03_c3_tail_modes.txt).
+    edges_on_side = False
+    #: streams the targets' chains of one capture are spread over (target i on stream i % tail_streams).  One: the chains
+    #: follow one another (each is a handful of small dependent kernels, latency-bound).
+    tail_streams = int(__import__("os").environ.get("IQA_TAIL_STREAMS", "1"))
+    #: the next capture's pass waits for this capture's chains (they then have the whole part to themselves -- for passes
+    #: whose workgroups leave no registers for another kernel's waves beside them)
+    pass_waits_for_tails = bool(int(__import__("os").environ.get("IQA_PASS_WAITS_FOR_TAILS", "0")))
 
     def __init__(self, targets: list, *, sample_rate: float, n_frames: int, chunk_size: int = 1_048_576,
                  fs_ch_target: float = 96_000.0, fmt: str = "s16", iq_order: str = "iq", precision_guard: float | None = None):
@@ -546,10 +559,23 @@ class ResidentBankRunner:
         for c in chans:
             c.plan_ahead()
         halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        if self.pass_waits_for_tails:
+            for ev in self.__dict__.pop("_tails_done", []):
+                main.wait_event(ev)
         if events:
             events[0].record()
         bank = ChannelBank(chans)
-        bank.process(raw_dev, outs=[p["z"] for p in slot["per"]], last_block=True, halo=halo, edge_stream=side)
+        # edges_on_side: True = the tails' stream (one queue: edges, combines and chains of the captures one after the other);
+        # "own" = a stream of their own -- the chains of capture i - 1, which find little room beside a pass whose workgroups fill
+        # the register files and finish late, then do not stand between pass i and its combine launches
+        edge = None if not self.edges_on_side or side is None else (D.side_stream("edge") if self.edges_on_side == "own" else side)
+        if edge is not None and edge is not side:
+            edge.wait_event(arrived)
+        bank.process(raw_dev, outs=[p["z"] for p in slot["per"]], last_block=True, halo=halo, edge_stream=edge)
+        if edge is not None and edge is not side:
+            combined = torch.cuda.Event()
+            combined.record(edge)
+            side.wait_event(combined)
         if events:
             events[1].record()
         self.last_bank_launches = getattr(bank, "launches", None) or [bank.last_launch]  # (one entry per shared launch of the capture)
@@ -562,13 +588,25 @@ class ResidentBankRunner:
             after_pass = torch.cuda.Event()
             after_pass.record(main)
             side.wait_event(after_pass)
-            with D.on_stream(side, main):
-                for per in slot["per"]:
+            sides = [side] + [D.side_stream(f"tail{k}") for k in range(1, max(1, min(self.tail_streams, len(slot["per"]))))]
+            for extra in sides[1:]:  # (behind the pass and behind what the first side stream had queued before it: probes, edges, combines)
+                behind_side = torch.cuda.Event()
+                behind_side.record(side)
+                extra.wait_event(behind_side)
+            for k, per in enumerate(slot["per"]):
+                st = sides[k % len(sides)]
+                with D.on_stream(st, main):
                     self._finish_target(per)
                     for key in ("z", "audio"):
-                        per[key].record_stream(side)
-                done = torch.cuda.Event()
-                done.record(side)
+                        per[key].record_stream(st)
+            done = torch.cuda.Event()
+            for extra in sides[1:]:
+                joined = torch.cuda.Event()
+                joined.record(extra)
+                side.wait_event(joined)
+            done.record(side)
+            if self.pass_waits_for_tails:
+                self._tails_done = [done]
         else:
             for per in slot["per"]:
                 self._finish_target(per)

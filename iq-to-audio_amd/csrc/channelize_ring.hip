@@ -93,6 +93,9 @@
 #ifndef IQA_RING_SPLIT_STAGE
 #define IQA_RING_SPLIT_STAGE 1
 #endif
+#ifndef IQA_RING_PAIR_LOADERS
+#define IQA_RING_PAIR_LOADERS 1  // 0: lane pairs keep their issuing / emitting multiplying waves and LDS-DMA (A/B)
+#endif
 #ifndef IQA_RING_SPLIT_F3_MAX_KS
 #define IQA_RING_SPLIT_F3_MAX_KS 8  // three rounds of loads in flight up to this many k steps, two beyond (registers)
 #endif
@@ -182,14 +185,17 @@ struct RingGeo {
     static constexpr int UNITS_ROW = PITCH / 16;
     static constexpr int NI_ROWS = (32 * UNITS_ROW + 63) / 64;
     static constexpr int SLOT_RAW = ROWS ? (32 * PITCH > 1024 * NI_ROWS ? 32 * PITCH : 1024 * NI_ROWS) : 1024 * NI;
-    static constexpr bool LOADERS = !PAIR && (ROWS || KS <= IQA_RING_LOADERS_MAX_KS);  // two extra waves feed the ring and emit (needs <= 168 registers)
+    // extra waves that feed the ring and emit (a wave then has 168 registers).  Lane pairs: with byte-plane staging up to 13 k
+    // steps -- four loader waves share the round's ONE tile, the first two emit a lane each
+    static constexpr bool LOADERS = (!PAIR && (ROWS || KS <= IQA_RING_LOADERS_MAX_KS)) ||
+                                    (PAIR1 && IQA_RING_SPLIT_STAGE != 0 && IQA_RING_PAIR_LOADERS != 0 && KS <= 13);
     // byte-plane staging (IQA_RING_SPLIT_STAGE): a slot is [high bytes: 32 rows at PLANE_PITCH][biased low bytes: ditto], the
     // same 1024 * NI bytes; the pitch is an odd number of 16-byte units (conflict-free ds_read_b128, lane = row).  FOUR
     // loader waves, two per parity (wave `half` of a parity takes the tile's 1 KiB pieces 2 j + half, j < KS), SPLIT_F rounds
     // of loads in flight in their registers (4 KS SPLIT_F of them), two slots per parity in LDS (one read, one written).
     static constexpr bool SPLIT = LOADERS && !U8 && (IQA_RING_SPLIT_STAGE != 0);
     static constexpr int PLANE_PITCH = 32 * KS + 16;
-    static constexpr int SPLIT_F = KS <= IQA_RING_SPLIT_F3_MAX_KS ? 3 : 2;  // (a loader wave has 168 registers: 4 KS SPLIT_F of data, 2 KS of offsets, the emission)
+    static constexpr int SPLIT_F = (PAIR || KS <= IQA_RING_SPLIT_F3_MAX_KS) ? 3 : 2;  // (a loader wave has 168 registers: 4 KS SPLIT_F of data, 2 KS of offsets, the emission)
     static constexpr int NLOADERS = SPLIT ? 4 : (LOADERS ? 2 : 0);
     static constexpr int SLOT = SPLIT ? 64 * PLANE_PITCH : SLOT_RAW;
     static constexpr int NDMA = ROWS ? NI_ROWS : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
@@ -428,17 +434,20 @@ struct __attribute__((packed, aligned(4))) ring_raw16 {  // 16 bytes of the capt
     int x, y, z, w;
 };
 
-template <int KS, int DBG, bool ACC64, bool ROWS, int HALF>
+// PAIR: the four loader waves (HALF 0..3) share the round's one tile, piece 4 j + HALF each; waves 0 and 1 emit lane 0's and
+// lane 1's outputs (c.cp = the lane; a, c.s_acc, c.tshift are that lane's), every group of their lane.
+template <int KS, int DBG, bool ACC64, bool ROWS, int HALF, bool PAIR = false>
 __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingCtx &c)
 {
-    constexpr int half = HALF;
+    constexpr bool EMITTER = PAIR ? HALF < 2 : HALF == 0;
     // pieces of a tile this wave takes: every second one, or -- from 12 k steps on, where 8 KS registers of data in flight
     // and the emission's float64 state do not fit one wave -- the emitting wave (half 0) the first KS - 2, the other the rest
-    constexpr bool UNEVEN = KS >= 12;
+    constexpr bool UNEVEN = !PAIR && KS >= 12;
     constexpr int P0 = UNEVEN ? KS - 2 : KS;
-    constexpr int NP = UNEVEN ? (HALF ? 2 * KS - P0 : P0) : KS;
-    auto piece = [](int j) { return UNEVEN ? (HALF ? P0 + j : j) : 2 * j + HALF; };
-    using G = RingGeo<KS, ROWS, false>;
+    constexpr int STRIDE = PAIR ? 4 : 2;
+    constexpr int NP = UNEVEN ? (HALF ? 2 * KS - P0 : P0) : (2 * KS + STRIDE - 1) / STRIDE;
+    auto piece = [](int j) { return UNEVEN ? (HALF ? P0 + j : j) : STRIDE * j + HALF; };
+    using G = RingGeo<KS, ROWS, false, PAIR>;
     constexpr int SLOT = G::SLOT, PP = G::PLANE_PITCH, F = G::SPLIT_F;
     constexpr bool STREAM = !(DBG & 16);
     const int cp = c.cp;
@@ -473,7 +482,8 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
     int4 buf[F][NP];
     auto request = [&](int round, auto set) {
         constexpr int S = decltype(set)::value;
-        const char *src = c.stream0 + static_cast<long long>(min(2 * round + cp, c.tiles - 1)) * c.tile_bytes;
+        // (PAIR: the stream runs on past this lane's own last tile for the partner that works pair_extra rounds behind)
+        const char *src = c.stream0 + static_cast<long long>(PAIR ? min(round, c.rounds - 1) : min(2 * round + cp, c.tiles - 1)) * c.tile_bytes;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             int so;
@@ -488,7 +498,7 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
     };
     auto stage = [&](int slot, auto set) {
         constexpr int S = decltype(set)::value;
-        char *hi0 = c.smem + (slot * 2 + cp) * SLOT;
+        char *hi0 = c.smem + (PAIR ? slot : slot * 2 + cp) * SLOT;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int4 d = buf[S][j];
@@ -520,39 +530,55 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
     static_assert(F == 2 || F == 3, "the prologue and the unrolled loop below are written for two or three rounds in flight");
     RingEmit em{1.0, 0.0};
     double st_re = a.rot64_re * a.rot64_re - a.rot64_im * a.rot64_im, st_im = 2.0 * a.rot64_re * a.rot64_im;  // 128 outputs
-    if (half == 0 && a.finalize && a.rotate) {
-        const unsigned long long m = static_cast<unsigned long long>(c.m0 + (64 * cp + 1 + c.lane - MF_Q));  // group cp
+    if (EMITTER && a.finalize && a.rotate) {
+        const unsigned long long m = static_cast<unsigned long long>(c.m0 + ((PAIR ? 0 : 64 * cp) + 1 + c.lane - MF_Q));  // its first group
         const unsigned long long ph = a.rot_base + m * a.rot_step;
         sincospi(2.0 * (static_cast<double>(ph >> 11) * (1.0 / 9007199254740992.0)), &em.ws, &em.wc);
     }
-    MfmaArgs a2 = a;  // ring_emit_group advances the rotation by (rot64_re, rot64_im): this wave owns every other group
-    a2.rot64_re = st_re;
-    a2.rot64_im = st_im;
+    MfmaArgs a2 = a;  // ring_emit_group advances the rotation by (rot64_re, rot64_im): without pairs this wave owns every other group
+    if constexpr (!PAIR) {
+        a2.rot64_re = st_re;
+        a2.rot64_im = st_im;
+    }
+    // the group of 64 outputs this wave emits in round r, or -1.  PAIR: a lane's group k (its tiles 2k, 2k + 1) in round
+    // 2k + 5 (lane 0) / 2k + 6 (lane 1) of the lane's own count, as ring_main's emitting waves did
+    auto group_of = [&](int r) {
+        if constexpr (PAIR) {
+            const int re = r - c.tshift, lag = 5 + cp;
+            return (re >= lag && ((re - lag) & 1) == 0) ? (re - lag) >> 1 : -1;
+        } else {
+            return (r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) ? r - RG_EMIT_LAG : -1;
+        }
+    };
     // The partial sums of the earlier passes (a long row's k-step ranges) are requested ONE ROUND AHEAD of their emission and
     // in front of that round's tile request: loads return in order, so waiting for a load issued behind the tile requests
     // -- where the emission uses it -- would wait for every tile in flight: the prefetch drained every other round.
     // (Up to 11 k steps; at 12 and 13 the four registers are not there, and the partial sums are loaded where they are used.)
-    constexpr bool PR_AHEAD = KS <= 11;
+    constexpr bool PR_AHEAD = PAIR || KS <= 11;
     double2 pr_next = make_double2(0.0, 0.0);
     auto round_body = [&](int r, auto set) {
         // (the planes of round r were written before this barrier: lgkmcnt(0) in front of it)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (STREAM && r + 1 < c.rounds) stage((r + 1) & 1, set);
         const double2 pr_now = pr_next;
-        if (PR_AHEAD && half == 0 && a.partial_in != nullptr && r + 1 >= RG_EMIT_LAG && ((r + 1 - RG_EMIT_LAG) & 1) == cp) {
-            const int i = 64 * (r + 1 - RG_EMIT_LAG) + 1 + c.lane - MF_Q;
-            pr_next = (i >= 0 && i < c.cnt) ? a.partial_in[c.i0 + i] : make_double2(0.0, 0.0);
+        if (PR_AHEAD && EMITTER && a.partial_in != nullptr) {
+            const int kn = group_of(r + 1);
+            if (kn >= 0) {
+                const int i = 64 * kn + 1 + c.lane - MF_Q;
+                pr_next = (i >= 0 && i < c.cnt) ? a.partial_in[c.i0 + i] : make_double2(0.0, 0.0);
+            }
         }
         if (STREAM) request(r + 1 + F, set);  // (beyond the last tile: the last tile again, never staged)
-        if (half == 0 && r >= RG_EMIT_LAG && ((r - RG_EMIT_LAG) & 1) == cp) {
+        const int k = EMITTER ? group_of(r) : -1;
+        if (k >= 0) {
             asm volatile("" ::: "memory");
             if constexpr (PR_AHEAD) {
                 RingEmitRegs g;  // (see ring_loader for why these sums are final)
-                ring_emit_load<ACC64, false>(a2, c, r - RG_EMIT_LAG, g);
+                ring_emit_load<ACC64, false>(a2, c, k, g);
                 g.pr = pr_now;
                 ring_emit_store<true>(a2, c, em, g);
             } else {
-                ring_emit_group<ACC64>(a2, c, em, r - RG_EMIT_LAG);
+                ring_emit_group<ACC64>(a2, c, em, k);
             }
             asm volatile("" ::: "memory");
         }
@@ -577,10 +603,17 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
         if (r < c.rounds) round_body(r, std::integral_constant<int, 1>{});
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (half == 0) {
+    if constexpr (EMITTER) {
         const int k_last = (c.cnt + 62) >> 6;
-        for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k)
-            if ((k & 1) == cp) ring_emit_group<ACC64>(a2, c, em, k);
+        if constexpr (PAIR) {
+            const int own = c.rounds - c.tshift, lag = 5 + cp;  // rounds in this lane's own count
+            const int k_next = own > lag ? ((own - 1 - lag) >> 1) + 1 : 0;
+            if (c.tshift < RG_PAIR_IDLE)  // (the idle half of a pair without a second lane emits nothing)
+                for (int k = k_next; k <= k_last; ++k) ring_emit_group<ACC64>(a2, c, em, k);
+        } else {
+            for (int k = max(c.rounds - RG_EMIT_LAG, 0); k <= k_last; ++k)
+                if ((k & 1) == cp) ring_emit_group<ACC64>(a2, c, em, k);
+        }
     }
 }
 
@@ -681,7 +714,11 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
     // parity 1's tile of round r - 1; barrier 2r + 1 is parity 1's boundary and parity 0's mid-tile barrier.  Every wave
     // executes the same 2 * rounds + 1 barriers: parity 1 one in front of its loop, parity 0 one behind it.
     constexpr bool STAGGER = (IQA_RING_STAGGER != 0) && !G::LOADERS;
-    constexpr bool DEFER_ADDS = DEFER && !STAGGER && (IQA_RING_DEFER != 0);  // (the older, weaker way of keeping a SIMD's two waves out of step)
+    // (the older, weaker way of keeping a SIMD's two waves out of step.  Not in the byte-plane kernels: with three waves per SIMD
+    // and no byte splits it buys nothing -- config 2's kernel 0.558 either way, 13 k steps 0.975 / 0.979 ms -- and its 32 held
+    // registers made the 64-bit-sum lane pairs spill: config 3 at the product's precisions 13.84 -> 12.65 ms without,
+    // profiles/r03_ab_defer.txt)
+    constexpr bool DEFER_ADDS = DEFER && !STAGGER && (IQA_RING_DEFER != 0) && !G::SPLIT;
     v16i_t held1 = zero16, held2 = zero16;  // DEFER_ADDS: the previous tile's sums, scattered at the start of the next round
     int held_t = -1;
     int slot = 0;
@@ -930,7 +967,7 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     RingCtx c;
     c.lane = tid & 63;
     c.rt = wave & 3;
-    c.cp = (wave >> 2) & 1;
+    c.cp = wave >= RG_WAVES ? (wave - RG_WAVES) & 1 : (wave >> 2) & 1;  // (loader waves: their parity, or the lane of a pair they emit)
     c.col = c.lane & 31;
     c.h = c.lane >> 5;
 
@@ -958,10 +995,16 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
 
     if constexpr (LOADERS) {
         if (wave >= RG_WAVES) {
-            c.cp = (wave - RG_WAVES) & 1;
             c.stream0 = stream;
             __syncthreads();
-            if constexpr (G::SPLIT) {
+            if constexpr (G::SPLIT && PAIR) {
+                switch (wave - RG_WAVES) {
+                    case 0: ring_loader_split<KS, DBG, ACC64, ROWS, 0, true>(a, c); break;
+                    case 1: ring_loader_split<KS, DBG, ACC64, ROWS, 1, true>(a, c); break;
+                    case 2: ring_loader_split<KS, DBG, ACC64, ROWS, 2, true>(a, c); break;
+                    default: ring_loader_split<KS, DBG, ACC64, ROWS, 3, true>(a, c); break;
+                }
+            } else if constexpr (G::SPLIT) {
                 if ((wave - RG_WAVES) >> 1) ring_loader_split<KS, DBG, ACC64, ROWS, 1>(a, c);
                 else ring_loader_split<KS, DBG, ACC64, ROWS, 0>(a, c);
             }
@@ -983,7 +1026,12 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
     }
     __syncthreads();
     c.stream0 = stream;
-    if constexpr (PAIR) {
+    if constexpr (PAIR && G::SPLIT) {
+        // loader waves feed the ring and emit: every multiplying wave only multiplies (parity 1 defers its adds)
+        constexpr int SA = SKIPK ? 2 : 0, SB = 0;  // (parity 0 = the pair's first lane)
+        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, true>(a, c, fq, std::integral_constant<int, SB>{});
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
+    } else if constexpr (PAIR) {
         // parity 0's first two waves feed the ring (one tile per round: the same KS + 1 instructions per issuing wave and
         // round as without pairs); one wave of either parity emits ITS lane's outputs; parity 1 defers its adds
         // (waves go to SIMDs cyclically: issuers on SIMDs 0 and 1, lane A's emitter -- wave 2 -- on SIMD 2, lane B's -- wave
@@ -1088,7 +1136,9 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
     // uniform: scalar loads from the kernel-argument segment.  PAIR: the table holds the pairs back to back, a workgroup
     // takes pair (idx mod n_pairs) and its waves of parity cp (waves 4..7: cp = 1) the pair's lane cp
     const int units = PAIR ? m.n_lanes >> 1 : m.n_lanes;
-    const int li = PAIR ? 2 * (idx % units) + ((__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) >> 2) & 1) : idx % units;
+    const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    // (loader waves 8, 10 carry the first lane's arguments, 9, 11 the second's: waves 8 and 9 emit those lanes)
+    const int li = PAIR ? 2 * (idx % units) + (wv >= RG_WAVES ? wv & 1 : (wv >> 2) & 1) : idx % units;
     const long long range_idx = static_cast<long long>(idx / units) * 8 + (blockIdx.x & 7);
     const RingLane &l = m.lane[li];
     MfmaArgs a = m.c;
@@ -1141,7 +1191,7 @@ __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>:
 
 // Two lanes per workgroup (RingGeo PAIR): the lanes of the table in pairs of equal tap-row group.
 template <int KS, bool ACC64 = false, bool SKIPK = false>
-__global__ __launch_bounds__((RingGeo<KS, false, false, true>::THREADS), 2) void k_channelize_mfma_s16_ring_pairs(RingMultiArgs m)
+__global__ __launch_bounds__((RingGeo<KS, false, false, true>::THREADS), (RingGeo<KS, false, false, true>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_pairs(RingMultiArgs m)
 {
     ring_multi_block<KS, false, false, true, ACC64, SKIPK>(m);
 }
