@@ -242,7 +242,7 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
 def _bank_traffic_ratio(tag_key: str):
     """(ratio, source) of measured HBM traffic over algorithmic bytes for a bank workload, from the committed rocprofv3 PMC
     summary (profiles/pmc_bank.sh); (None, reason) when no matching profile is committed."""
-    for name in ("r03_bank_pmc_summary.json", "r02c_bank_pmc_summary.json"):
+    for name in ("r03b_bank_pmc_summary.json", "r03bf_bank_pmc_summary.json", "r03_bank_pmc_summary.json", "r02c_bank_pmc_summary.json"):
         path = ROOT / "profiles" / name
         if not path.exists():
             continue

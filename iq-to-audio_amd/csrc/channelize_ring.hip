@@ -93,6 +93,9 @@
 #ifndef IQA_RING_SPLIT_STAGE
 #define IQA_RING_SPLIT_STAGE 1
 #endif
+#ifndef IQA_RING_SPLIT_CONTIG
+#define IQA_RING_SPLIT_CONTIG 0  // 1: a parity's two loader waves take the first and the second half of a tile instead of every second piece (A/B)
+#endif
 #ifndef IQA_RING_PAIR_LOADERS
 #define IQA_RING_PAIR_LOADERS 1  // 0: lane pairs keep their issuing / emitting multiplying waves and LDS-DMA (A/B)
 #endif
@@ -442,8 +445,8 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
     constexpr bool EMITTER = PAIR ? HALF < 2 : HALF == 0;
     // pieces of a tile this wave takes: every second one, or -- from 12 k steps on, where 8 KS registers of data in flight
     // and the emission's float64 state do not fit one wave -- the emitting wave (half 0) the first KS - 2, the other the rest
-    constexpr bool UNEVEN = !PAIR && KS >= 12;
-    constexpr int P0 = UNEVEN ? KS - 2 : KS;
+    constexpr bool UNEVEN = !PAIR && (KS >= 12 || IQA_RING_SPLIT_CONTIG != 0);
+    constexpr int P0 = KS >= 12 ? KS - 2 : KS;
     constexpr int STRIDE = PAIR ? 4 : 2;
     constexpr int NP = UNEVEN ? (HALF ? 2 * KS - P0 : P0) : (2 * KS + STRIDE - 1) / STRIDE;
     auto piece = [](int j) { return UNEVEN ? (HALF ? P0 + j : j) : STRIDE * j + HALF; };
