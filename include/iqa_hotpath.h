@@ -132,11 +132,11 @@ int iqa_channelize(const iqa_chan_params *p, const void *taps_dev, const void *r
 typedef struct {
     int32_t outputs_per_block; /* multiple of 32; LDS = afrag + 16*(outputs_per_block+160) bytes <= 160 KiB */
     int32_t reserved;          /* data-path variant + diagnostics flags.  0 = per-lane row loads; 64 = block-wide
-                                * LDS-DMA ring, 64-bit sums (needs iqa_mfma_ring_mode(fmt, D, k_first, k_count, 0) != 0;
+                                * ring through LDS (byte planes staged by loader waves, or LDS-DMA), 64-bit sums (needs iqa_mfma_ring_mode(fmt, D, k_first, k_count, 0) != 0;
                                 * its LDS does not depend on outputs_per_block); 64|128 = the ring with 256*S1 + S2
                                 * in one int32, for fragments from a quantisation that bounds that sum
                                 * (dsp_plan.plan_mfma(acc32=True); iqa_mfma_ring_mode(fmt, D, k_first, k_count, 1) != 0);
-                                * bits 0,1,4,5 are timing diagnostics, never set in production; 256 = the low tap byte
+                                * bits 0..5 are timing diagnostics, never set in production; 256 = the low tap byte
                                 * of these fragments is zero throughout (a hint: the multi-lane launches act on it, lane bit 1) */
     double unit;               /* value of one tap LSB (ingest scale folded in) */
     double c_re, c_im;         /* 128 * sum of quantised taps per output component (low-byte bias) */

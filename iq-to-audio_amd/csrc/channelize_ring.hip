@@ -22,6 +22,13 @@
 //     block is not bounded by LDS: every CU gets ONE contiguous range of the launch (persistent blocks:
 //     one prologue per CU, 63 rows of halo per CU).
 //
+// Round 3: up to 13 k steps (and in every row-staged int16 kernel) the LDS-DMA copies are replaced by LOADER WAVES that fetch
+// the tiles into registers, split every int16 into its high byte and its biased low byte once per tile and write two byte
+// planes per slot; the multiplying waves read their MFMA operands as they lie in LDS (IQA_RING_SPLIT_STAGE below says what
+// that bought).  The ring of such a kernel is two slots per parity in LDS plus two or three rounds of loads in the loaders'
+// registers; the loaders also emit.  The text above describes the LDS-DMA form, which remains for uint8 captures and for
+// 14..16 k steps.
+//
 // A contiguous slot is 1024*(2*KS + 1) bytes >= 32 rows at a pitch of D/4 (+1) 16-byte units (KS = ceil(2D/32) k steps;
 // the K padding of the last k step reads on into the next row, against zero taps); a tile takes 2*KS + 1 DMA
 // instructions; it needs D % 4 == 0 (16-byte aligned rows for ds_read_b128) and KS <= 16.
