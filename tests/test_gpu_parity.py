@@ -1062,6 +1062,45 @@ def test_mfma_ring_kernel_matches_the_per_lane_kernel(A, fs, d, bw, n, acc32):
         assert rms(ring - ref) < tol[0] * scale and np.abs(ring - ref).max() < tol[1] * scale, other
 
 
+@pytest.mark.parametrize("precision", ["fast", "full"])
+@pytest.mark.parametrize("d", [16 * ks for ks in range(1, 17)] + [16 * ks - 3 for ks in (1, 2, 3, 5, 7, 8, 9, 10, 11)] + [100, 212])
+def test_ring_kernel_every_kstep_count(A, d, precision):
+    """Every instantiation of the ring kernel once: contiguous slots at 1..16 k steps (D = 16 KS: byte planes staged by
+    loader waves up to 13 k steps -- tables of offsets up to 8, packed offsets beyond, uneven piece split at 12 and 13 --,
+    LDS-DMA by the multiplying waves at 14..16), row-staged slots at 1..11 k steps (odd D: dword-aligned rows), a row that
+    does not fill its last k step (D = 100, 212); 32-bit sums ("fast") and 64-bit sums ("full": the variants that spill a
+    few registers at 12-13 k steps).  Against the float32 VALU kernel on a ragged capture cut into two blocks."""
+    import torch
+
+    from iq_to_audio_amd import _dev as D
+    from iq_to_audio_amd import processing as PR
+
+    fs = 96_000.0 * d
+    n = 4500 * d + 1237
+    f_off = 0.0917 * fs
+    raw = D.to_device(O.synth_capture_s16(fs, n / fs, f_off).reshape(-1), "int16")
+    taps = A.design_channel_filter(fs, 12_500.0, d)
+    old = (PR._ChannelKernel.mfma_min_outputs, PR._ChannelKernel.use_mfma)
+    outs = {}
+    try:
+        PR._ChannelKernel.mfma_min_outputs = 1024
+        for use in (False, True):
+            PR._ChannelKernel.use_mfma = use
+            ch = A.Channelizer(taps, sample_rate=fs, freq_offset=f_off, mix_sign=1, decimation=d, precision=precision)
+            cut = 2 * (2000 * d + 77)
+            outs[use] = torch.cat([ch.process(raw[:cut]), ch.process(raw[cut:])]).cpu().numpy()
+            if use:
+                assert ch._kernel.last_kernel.startswith("k_channelize_mfma_s16"), ch._kernel.last_kernel
+    finally:
+        PR._ChannelKernel.mfma_min_outputs, PR._ChannelKernel.use_mfma = old
+    valu, mfma = outs[False], outs[True]
+    assert valu.shape == mfma.shape == (-(-n // d),)
+    assert float(np.abs(valu).max()) > 0.05  # (the carrier is in the channel)
+    # of full scale: ~14-bit taps for "fast"; the VALU kernel's own float32 rounding bounds what "full" can be held to
+    tol = (2e-5, 1.2e-4) if precision == "fast" else (5e-7, 4e-6)
+    assert rms(mfma - valu) < tol[0] and np.abs(mfma - valu).max() < tol[1], (rms(mfma - valu), np.abs(mfma - valu).max())
+
+
 @pytest.mark.parametrize("fs,d,bw,n", [(2.4e6, 25, 12500.0, 6_000_000), (10e6, 104, 12500.0, 9_000_000), (50e6, 521, 12500.0, 16_000_000)])
 def test_mfma_ring_kernel_uint8_captures(A, fs, d, bw, n):
     """uint8 I/Q captures (cu8, RTL-SDR style: 2.4 MS/s -> D = 25, an odd row of 50 bytes) on the matrix cores: the
