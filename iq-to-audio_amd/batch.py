@@ -568,9 +568,11 @@ class ResidentBankRunner:
         # edges_on_side: True = the tails' stream (one queue: edges, combines and chains of the captures one after the other);
         # "own" = a stream of their own -- the chains of capture i - 1, which find little room beside a pass whose workgroups fill
         # the register files and finish late, then do not stand between pass i and its combine launches
-        edge = None if not self.edges_on_side or side is None else (D.side_stream("edge") if self.edges_on_side == "own" else side)
+        own = self.edges_on_side in ("own", "edges")
+        edge = None if not self.edges_on_side or side is None else (D.side_stream("edge") if own else side)
         if edge is not None and edge is not side:
             edge.wait_event(arrived)
+        bank.combines_on_edge_stream = self.edges_on_side != "edges"  # "edges": only the edge launches leave the caller's stream
         bank.process(raw_dev, outs=[p["z"] for p in slot["per"]], last_block=True, halo=halo, edge_stream=edge)
         if edge is not None and edge is not side:
             combined = torch.cuda.Event()

@@ -662,6 +662,7 @@ class ChannelBank:
                 for acc32 in widths:
                     lanes = [i for i in capable if self.chans[i]._kernel.acc32 == acc32]
                     sub = ChannelBank([self.chans[i] for i in lanes])
+                    sub.combines_on_edge_stream = self.combines_on_edge_stream
                     got = sub.process(raw, outs=[outs[i] for i in lanes], last_block=last_block, halo=halo, edge_stream=edge_stream)
                     self.launches.append(sub.last_launch)
                     if self.last_launch is None:
@@ -716,6 +717,8 @@ class ChannelBank:
                c_int64(m_first), c_int64(n_out), N.stream_ptr())
         self.last_launch = dict(lanes=len(kernels), launches=1, combines=0, pairs=0)
         return True
+
+    combines_on_edge_stream = True  # (False: the combine launches stay on the caller's stream, only the float32 edge launches go to ``edge_stream``)
 
     def _run_shared(self, x, n: int, m_first: int, n_out: int, outs: list, halo, edge_stream=None, interior_only: bool = False):
         kernels = [c._kernel for c in self.chans]
@@ -804,7 +807,7 @@ class ChannelBank:
                 part = ids[lo : lo + self.MAX_LANES]
                 launch(part, "iqa_channelize_mfma_multi", len(part))
         main = None
-        if edge_stream is not None and any(len(mp.groups) > 1 for mp in plans):
+        if edge_stream is not None and self.combines_on_edge_stream and any(len(mp.groups) > 1 for mp in plans):
             # the combine launches go where the consumers of the outputs are queued (behind the pass): the caller's stream
             # then holds the pass alone.  (No stream calls at all otherwise: this function also runs inside graph captures,
             # where a set_stream -- even to the current stream -- made the replays 2.5x slower.)
