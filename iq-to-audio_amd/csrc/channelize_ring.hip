@@ -107,7 +107,10 @@
 #define IQA_RING_PAIR_LOADERS 1  // 0: lane pairs keep their issuing / emitting multiplying waves and LDS-DMA (A/B)
 #endif
 #ifndef IQA_RING_SPLIT_F3_MAX_KS
-#define IQA_RING_SPLIT_F3_MAX_KS 8  // three rounds of loads in flight up to this many k steps, two beyond (registers)
+#define IQA_RING_SPLIT_F3_MAX_KS 0  // three rounds of loads in flight up to this many k steps, two beyond.  Two everywhere: config 2's
+                                    // kernel measures the same with two and three (0.547 / 0.549 ms, profiles/r03b_ab_rounds_in_flight.txt),
+                                    // and with two a workgroup of the 7-k-step kernel takes 3 x 120 registers per SIMD instead of 3 x 152:
+                                    // the 80-register kernels of a capture's tail fit beside it
 #endif
 
 #include <atomic>
