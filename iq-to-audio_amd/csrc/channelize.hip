@@ -152,6 +152,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_channelize_v1(ChanArgs a)
 
     for (int tc = 0; tc < a.Lpad; tc += CH_TCH) {
         const int cnt = min(CH_TCH, a.Lpad - tc);
+        // (block-uniform) a slice of taps whose frames lie in front of the stream for every output of the block -- the
+        // start-up outputs of a capture, no history: zeros -- or behind the block's last frame contributes nothing: the
+        // head edge of a long filter skips most of its slices this way
+        if (a.hist == nullptr && blk_last + tc + cnt <= 0) continue;
+        if (blk_first + tc >= a.n_frames) break;
         __syncthreads();
         for (int t = tid * 2; t < cnt; t += CH_THREADS * 2) {
             const float4 g = *reinterpret_cast<const float4 *>(&a.taps[tc + t]);

@@ -100,6 +100,9 @@
 #ifndef IQA_RING_SPLIT_STAGE
 #define IQA_RING_SPLIT_STAGE 1
 #endif
+#ifndef IQA_RING_PD
+#define IQA_RING_PD 2
+#endif
 #ifndef IQA_RING_SPLIT_CONTIG
 #define IQA_RING_SPLIT_CONTIG 0  // 1: a parity's two loader waves take the first and the second half of a tile instead of every second piece (A/B)
 #endif
@@ -823,7 +826,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
             // so it never moves a ds_read above an earlier issue(): the refill in front of this loop is a fence for them).
             auto tile_body = [&](auto skip_low) {
                 constexpr bool SKIP_LOW = decltype(skip_low)::value;  // q2 == 0 throughout: no q2*hi product
-                constexpr int PD = KS < 2 ? KS : 2;
+                constexpr int PD = KS < IQA_RING_PD ? KS : IQA_RING_PD;  // k steps the fragment reads run ahead of the MFMAs
                 v16i_t acc1, acc2;
                 if constexpr (U8) {
                     // uint8 frames: this lane's 16 bytes of a k step are 8 frames; u ^ 0x80 = u - 128 as int8
