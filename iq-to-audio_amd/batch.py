@@ -7,6 +7,8 @@ streams, events, buffer slots -- no arithmetic.
 """
 from __future__ import annotations
 
+import contextlib
+
 from ctypes import c_int32, c_int64, c_void_p
 
 import numpy as np
@@ -458,6 +460,8 @@ class ResidentBankRunner:
     # next pass -- waited: config 3 measured 13.6 ms per capture (= everything on one stream) against 13.2-13.3 with them on
     # the caller's stream (profiles/r03_c3_tail_modes.txt).
     edges_on_side = False
+    #: the mixer-sign probes of a capture on the tails' stream (read at ``collect`` only) instead of the caller's, in front of its pass
+    probes_on_side = bool(int(__import__("os").environ.get("IQA_PROBES_ON_SIDE", "0")))
     #: streams the targets' chains of one capture are spread over (target i on stream i % tail_streams).  One: the chains
     #: follow one another (each is a handful of small dependent kernels, latency-bound).
     tail_streams = int(__import__("os").environ.get("IQA_TAIL_STREAMS", "1"))
@@ -541,6 +545,18 @@ class ResidentBankRunner:
         # the running pass until it ends, one per pass boundary; through the float32 kernel -- MixSignProbe(matrix_cores=
         # False) -- they fit beside it but the long filters' probes then take longer than the pass has room for: 10.4
         # against 9.4 ms per capture at config 3)
+        probe_ctx = D.on_stream(side, main) if (self.probes_on_side and side is not None) else contextlib.nullcontext()
+        with probe_ctx:
+            probes = self._queue_probes(warm, slot)
+        signs = [s["mix_sign"] if s["mix_sign"] in (1, -1) else sp for s, sp in zip(self.targets, self._spec_sign)]
+        precisions = list(self._spec_precision)
+        chans = [self._channelizer(s, sg, pr) for s, sg, pr in zip(self.targets, signs, precisions)]
+        for c in chans:
+            c.plan_ahead()
+        halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        return self._submit_rest(raw_dev, slot, probes, signs, precisions, chans, halo, events, main, side, arrived if side is not None else None)
+
+    def _queue_probes(self, warm, slot) -> list:
         todo = [i for i, s in enumerate(self.targets) if s["mix_sign"] not in (1, -1)]
         grouped = probe_targets(warm, self.fs, [(self.targets[i]["freq_offset"], self.targets[i]["taps"]) for i in todo], self.d,
                                 fmt=self.fmt, iq_order=self.iq_order, host=slot["probe_host"]) if len(todo) > 1 else None
@@ -553,12 +569,10 @@ class ResidentBankRunner:
                       MixSignProbe(warm, self.fs, s["freq_offset"], s["taps"], self.d, fmt=self.fmt, iq_order=self.iq_order,
                                    measure_level=self._guarded(s))
                       for s in self.targets]
-        signs = [s["mix_sign"] if s["mix_sign"] in (1, -1) else sp for s, sp in zip(self.targets, self._spec_sign)]
-        precisions = list(self._spec_precision)
-        chans = [self._channelizer(s, sg, pr) for s, sg, pr in zip(self.targets, signs, precisions)]
-        for c in chans:
-            c.plan_ahead()
-        halo = (enclosing, int(lead_frames)) if enclosing is not None else None
+        return probes
+
+    def _submit_rest(self, raw_dev, slot, probes, signs, precisions, chans, halo, events, main, side, arrived) -> dict:
+        torch = D.torch_mod()
         if self.pass_waits_for_tails:
             for ev in self.__dict__.pop("_tails_done", []):
                 main.wait_event(ev)

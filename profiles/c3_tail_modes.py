@@ -9,8 +9,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench  # noqa: E402
 from iq_to_audio_amd.batch import ResidentBankRunner as R  # noqa: E402
 
-modes = [dict(), dict(edges_on_side="edges"), dict(edges_on_side="edges", tail_streams=3), dict(), dict(edges_on_side="edges")]
-defaults = dict(overlap_tails=True, edges_on_side=False, tail_streams=1, pass_waits_for_tails=False)
+modes = [dict(), dict(probes_on_side=True), dict(), dict(probes_on_side=True)]
+defaults = dict(overlap_tails=True, edges_on_side=False, tail_streams=1, pass_waits_for_tails=False, probes_on_side=False)
 for m in modes:
     for k, v in {**defaults, **m}.items():
         setattr(R, k, v)
