@@ -106,6 +106,9 @@
 #ifndef IQA_RING_SPLIT_CONTIG
 #define IQA_RING_SPLIT_CONTIG 0  // 1: a parity's two loader waves take the first and the second half of a tile instead of every second piece (A/B)
 #endif
+#ifndef IQA_RING_PAIR_NLOADERS
+#define IQA_RING_PAIR_NLOADERS 4
+#endif
 #ifndef IQA_RING_PAIR_LOADERS
 #define IQA_RING_PAIR_LOADERS 1  // 0: lane pairs keep their issuing / emitting multiplying waves and LDS-DMA (A/B)
 #endif
@@ -211,8 +214,10 @@ struct RingGeo {
     // of loads in flight in their registers (4 KS SPLIT_F of them), two slots per parity in LDS (one read, one written).
     static constexpr bool SPLIT = LOADERS && !U8 && (IQA_RING_SPLIT_STAGE != 0);
     static constexpr int PLANE_PITCH = 32 * KS + 16;
-    static constexpr int SPLIT_F = (PAIR || KS <= IQA_RING_SPLIT_F3_MAX_KS) ? 3 : 2;  // (a loader wave has 168 registers: 4 KS SPLIT_F of data, 2 KS of offsets, the emission)
-    static constexpr int NLOADERS = SPLIT ? 4 : (LOADERS ? 2 : 0);
+    static constexpr int SPLIT_F = ((PAIR && IQA_RING_PAIR_NLOADERS == 4) || KS <= IQA_RING_SPLIT_F3_MAX_KS) ? 3 : 2;  // (a loader wave has 168 registers: 4 KS SPLIT_F of data, 2 KS of offsets, the emission)
+    // (lane pairs: IQA_RING_PAIR_NLOADERS loader waves, 2 or 4.  Two: ten waves per workgroup -- SIMDs 2 and 3 hold two waves
+    // each and keep 176 registers free, room for a 256-thread workgroup of the small kernels of a capture's tail)
+    static constexpr int NLOADERS = SPLIT ? (PAIR ? IQA_RING_PAIR_NLOADERS : 4) : (LOADERS ? 2 : 0);
     static constexpr int SLOT = SPLIT ? 64 * PLANE_PITCH : SLOT_RAW;
     static constexpr int NDMA = ROWS ? NI_ROWS : (LOADERS ? NI : KS + 1);  // DMAs per issuing wave and round
     static constexpr int FIT = (160 * 1024 - ACCS * RG_ACC_BYTES) / (TPR * SLOT);
@@ -460,7 +465,7 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
     // and the emission's float64 state do not fit one wave -- the emitting wave (half 0) the first KS - 2, the other the rest
     constexpr bool UNEVEN = !PAIR && (KS >= 12 || IQA_RING_SPLIT_CONTIG != 0);
     constexpr int P0 = KS >= 12 ? KS - 2 : KS;
-    constexpr int STRIDE = PAIR ? 4 : 2;
+    constexpr int STRIDE = PAIR ? RingGeo<KS, ROWS, false, PAIR>::NLOADERS : 2;
     constexpr int NP = UNEVEN ? (HALF ? 2 * KS - P0 : P0) : (2 * KS + STRIDE - 1) / STRIDE;
     auto piece = [](int j) { return UNEVEN ? (HALF ? P0 + j : j) : STRIDE * j + HALF; };
     using G = RingGeo<KS, ROWS, false, PAIR>;
@@ -1013,7 +1018,10 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
         if (wave >= RG_WAVES) {
             c.stream0 = stream;
             __syncthreads();
-            if constexpr (G::SPLIT && PAIR) {
+            if constexpr (G::SPLIT && PAIR && G::NLOADERS == 2) {
+                if (wave - RG_WAVES) ring_loader_split<KS, DBG, ACC64, ROWS, 1, true>(a, c);
+                else ring_loader_split<KS, DBG, ACC64, ROWS, 0, true>(a, c);
+            } else if constexpr (G::SPLIT && PAIR) {
                 switch (wave - RG_WAVES) {
                     case 0: ring_loader_split<KS, DBG, ACC64, ROWS, 0, true>(a, c); break;
                     case 1: ring_loader_split<KS, DBG, ACC64, ROWS, 1, true>(a, c); break;

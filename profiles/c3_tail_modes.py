@@ -6,10 +6,16 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os  # noqa: E402
+
+from iq_to_audio_amd import _native as NATIVE  # noqa: E402
+
+if os.environ.get("IQA_LIB"):  # an experiment build of the library
+    NATIVE.LIB_PATH = Path(os.environ["IQA_LIB"]).resolve()
 import bench  # noqa: E402
 from iq_to_audio_amd.batch import ResidentBankRunner as R  # noqa: E402
 
-modes = [dict(), dict(probes_on_side=True), dict(), dict(probes_on_side=True)]
+modes = [dict(), dict(edges_on_side=True), dict()] if os.environ.get("IQA_LIB") else [dict(), dict(probes_on_side=True), dict(), dict(probes_on_side=True)]
 defaults = dict(overlap_tails=True, edges_on_side=False, tail_streams=1, pass_waits_for_tails=False, probes_on_side=False)
 for m in modes:
     for k, v in {**defaults, **m}.items():
