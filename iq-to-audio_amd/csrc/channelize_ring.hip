@@ -100,6 +100,9 @@
 #ifndef IQA_RING_SPLIT_STAGE
 #define IQA_RING_SPLIT_STAGE 1
 #endif
+#ifndef IQA_RING_HALF_STEP
+#define IQA_RING_HALF_STEP 1  // 0: the last k step of a row is always a whole 32x32x32 MFMA (A/B)
+#endif
 #ifndef IQA_RING_PD
 #define IQA_RING_PD 2
 #endif
@@ -241,6 +244,7 @@ struct RingCtx {
     int row_units, pitch_units;  // contiguous slots: 16-byte units per data row in the capture / in LDS (odd)
     int tshift;  // lane pairs: this wave's own tile t is the staged tile of round t + tshift (0 without pairs)
     int extra;   // lane pairs: rounds the workgroup runs beyond a lane's own tiles (the second lane works that far behind)
+    int half_last;  // byte-plane kernels, contiguous slots: the row's last k step holds <= 16 values -- it is a 32x32x16 MFMA
 };
 
 // Source offset (bytes from the tile's first byte) of the 16 bytes lane `lane` of DMA instruction `idx` fetches: the
@@ -646,7 +650,7 @@ __device__ __forceinline__ void ring_loader_split(const MfmaArgs &a, const RingC
 // SKIP: what this wave does with the q2*hi product (the third matrix instruction of a k step): 0 = always computes it;
 // 2 = never (its lane's low tap byte is zero throughout: the first lane of a "fine" / "full" tap-row group); 1 = asks the
 // lane's flag at run time (both bodies in the code: ~30 registers more, so only the kernels of such launches carry it).
-template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER, bool PAIR, typename SKIPT>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool ISSUER, bool EMIT, bool DEFER, bool PAIR, typename SKIPT, bool HALF = false>
 __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, const v4i_t (&fq)[KS][2], SKIPT)
 {
     constexpr int SKIP = SKIPT::value;
@@ -854,20 +858,35 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
                 if constexpr (G::SPLIT) {
                     // byte planes: the operands as they lie in the slot (high bytes at la, biased low bytes 32 rows further)
                     v4i_t hh[KS], ll[KS];
+                    constexpr bool half_last = HALF;  // (a property of the kernel variant: both bodies in one kernel cost ~25 registers)
+                    auto fetch = [&](int ks) {  // `ks` is a compile-time constant at every call site
+                        if (ks == KS - 1 && half_last) {  // this lane's 8 values of the half step: 8 h bytes into the step, not 16 h
+                            const int2 h2 = *reinterpret_cast<const int2 *>(la - 8 * c.h + 32 * ks);
+                            const int2 l2 = *reinterpret_cast<const int2 *>(la - 8 * c.h + 32 * G::PLANE_PITCH + 32 * ks);
+                            hh[ks].x = h2.x;
+                            hh[ks].y = h2.y;
+                            ll[ks].x = l2.x;
+                            ll[ks].y = l2.y;
+                        } else {
+                            hh[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * ks);
+                            ll[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * G::PLANE_PITCH + 32 * ks);
+                        }
+                    };
 #pragma unroll
-                    for (int ks = 0; ks < PD; ++ks) {
-                        hh[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * ks);
-                        ll[ks] = *reinterpret_cast<const v4i_t *>(la + 32 * G::PLANE_PITCH + 32 * ks);
-                    }
+                    for (int ks = 0; ks < PD; ++ks) fetch(ks);
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         const v4i_t hi = hh[ks], lo = ll[ks];
-                        if (ks + PD < KS) {
-                            hh[ks + PD] = *reinterpret_cast<const v4i_t *>(la + 32 * (ks + PD));
-                            ll[ks + PD] = *reinterpret_cast<const v4i_t *>(la + 32 * G::PLANE_PITCH + 32 * (ks + PD));
-                        }
+                        if (ks + PD < KS) fetch(ks + PD);
                         if (DBG & 32) {
                             asm volatile("" ::"v"(hi), "v"(lo));
+                        } else if (ks == KS - 1 && half_last) {
+                            auto pack = [](int x, int y) { return static_cast<long>((static_cast<unsigned long long>(static_cast<unsigned>(y)) << 32) | static_cast<unsigned>(x)); };
+                            const long a1 = pack(fq[ks][0].x, fq[ks][0].y), a2 = pack(fq[ks][1].x, fq[ks][1].y);
+                            const long bh = pack(hi.x, hi.y), bl = pack(lo.x, lo.y);
+                            acc1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1, bh, ks ? acc1 : zero16, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1, bl, ks ? acc2 : zero16, 0, 0, 0);
+                            if constexpr (!SKIP_LOW) acc2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a2, bh, acc2, 0, 0, 0);
                         } else {
                             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], hi, ks ? acc1 : zero16, 0, 0, 0);
                             acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fq[ks][0], lo, ks ? acc2 : zero16, 0, 0, 0);
@@ -976,7 +995,7 @@ __device__ __forceinline__ void ring_main(const MfmaArgs &a, const RingCtx &c, c
 // SKIPK (kernels of launches in which some lanes have high-byte-only taps, see ring_main's SKIP): lane pairs -- the pair's
 // first lane (parity 0) skips the q2*hi product at compile time, the second never does (the host pairs a tap-row group's
 // high-byte lane with its residue lane); one lane per workgroup -- every wave asks its lane's flag.
-template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool PAIR = false, bool SKIPK = false>
+template <int KS, int DBG, bool ACC64, bool ROWS, bool U8, bool PAIR = false, bool SKIPK = false, bool HALF = false>
 __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_idx)
 {
     using G = RingGeo<KS, ROWS, U8, PAIR>;
@@ -1048,6 +1067,24 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(fq[ks][0]), "v"(fq[ks][1]));
     }
+    // A row of 2 D values whose last k step holds at most 16 of them (D = 104: 208 = 6 x 32 + 16): the other half of that
+    // step multiplied padding against zero taps.  The byte planes make the half step a v_mfma_i32_32x32x16_i8 -- lanes 0..31
+    // take values 0..7 of the step, lanes 32..63 values 8..15: the tap fragment's first 8 bytes, and for the upper lanes the
+    // second 8 bytes of the lane 32 below (whose own bytes were the padding's zero taps); the data are two ds_read_b64.
+    // (The kernel variant HALF: the launcher picks it for rows of 32 (KS - 1) + 1 .. 16 values.)
+    c.half_last = HALF;
+    if constexpr (HALF) {
+        static_assert(!ROWS && !U8 && !PAIR, "the half last k step exists for single lanes over contiguous byte-plane slots");
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const v4i_t f = fq[KS - 1][pc];
+            const int z0 = __shfl(f.z, c.lane ^ 32, kWave), w0 = __shfl(f.w, c.lane ^ 32, kWave);
+            if (c.h) {
+                fq[KS - 1][pc].x = z0;
+                fq[KS - 1][pc].y = w0;
+            }
+        }
+    }
     __syncthreads();
     c.stream0 = stream;
     if constexpr (PAIR && G::SPLIT) {
@@ -1080,8 +1117,8 @@ __device__ __forceinline__ void ring_block(const MfmaArgs &a, long long range_id
         else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, true>(a, c, fq, std::integral_constant<int, SA>{});
     } else if constexpr (LOADERS) {
         constexpr int S1 = SKIPK ? 1 : 0;
-        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, false>(a, c, fq, std::integral_constant<int, S1>{});
-        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, false>(a, c, fq, std::integral_constant<int, S1>{});
+        if (c.cp) ring_main<KS, DBG, ACC64, ROWS, U8, false, false, true, false, std::integral_constant<int, S1>, HALF>(a, c, fq, std::integral_constant<int, S1>{});
+        else ring_main<KS, DBG, ACC64, ROWS, U8, false, false, false, false, std::integral_constant<int, S1>, HALF>(a, c, fq, std::integral_constant<int, S1>{});
     } else {
         constexpr int S1 = SKIPK ? 1 : 0;
         // one issuing wave per SIMD (waves go to SIMDs in a cyclic order of period 4): rt 0,1 of parity 0, rt 2,3 of parity 1
@@ -1098,6 +1135,14 @@ template <int KS, int DBG, bool ACC64>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring(MfmaArgs a)
 {
     ring_block<KS, DBG, ACC64, false, false>(a, blockIdx.x);
+}
+
+// The variant whose last k step is a 32x32x16 MFMA (rows of 32 (KS - 1) + 1 .. 16 values: D = 104 -> 208 = 6 x 32 + 16).
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, false>::THREADS), 3) void k_channelize_mfma_s16_ring_half(MfmaArgs a)
+{
+    static_assert(RingGeo<KS, false>::SPLIT, "byte-plane kernels only");
+    ring_block<KS, 0, false, false, false, false, false, true>(a, blockIdx.x);
 }
 
 // The same block under its own name for short launches (the mixer-sign probes: a few thousand outputs in blocks of
@@ -1153,7 +1198,7 @@ struct RingMultiArgs {
     RingLane lane[RG_MAX_LANES];
 };
 
-template <int KS, bool ROWS, bool U8, bool PAIR = false, bool ACC64 = false, bool SKIPK = false>
+template <int KS, bool ROWS, bool U8, bool PAIR = false, bool ACC64 = false, bool SKIPK = false, bool HALF = false>
 __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
 {
     const int idx = blockIdx.x >> 3;
@@ -1202,7 +1247,7 @@ __device__ __forceinline__ void ring_multi_block(const RingMultiArgs &m)
         a.pace_slot = static_cast<int>(range_idx) * units + idx % units;
     }
     if (range_idx * a.range >= a.n_out) return;  // (the last ranges of a short launch)
-    ring_block<KS, 0, ACC64, ROWS, U8, PAIR, SKIPK>(a, range_idx);
+    ring_block<KS, 0, ACC64, ROWS, U8, PAIR, SKIPK, HALF>(a, range_idx);
 }
 
 // ACC64: one int64 (S1 << 32) + S2 per output component instead of one int32 256*S1 + S2 -- 16-bit taps without the int32
@@ -1211,6 +1256,14 @@ template <int KS, bool ACC64 = false, bool SKIPK = false>
 __global__ __launch_bounds__((RingGeo<KS, false>::THREADS), (RingGeo<KS, false>::LOADERS ? 3 : 2)) void k_channelize_mfma_s16_ring_multi(RingMultiArgs m)
 {
     ring_multi_block<KS, false, false, false, ACC64, SKIPK>(m);
+}
+
+// ... with the row's last k step as a 32x32x16 MFMA (see k_channelize_mfma_s16_ring_half).
+template <int KS>
+__global__ __launch_bounds__((RingGeo<KS, false>::THREADS), 3) void k_channelize_mfma_s16_ring_multi_half(RingMultiArgs m)
+{
+    static_assert(RingGeo<KS, false>::SPLIT, "byte-plane kernels only");
+    ring_multi_block<KS, false, false, false, false, false, true>(m);
 }
 
 // Two lanes per workgroup (RingGeo PAIR): the lanes of the table in pairs of equal tap-row group.
@@ -1261,6 +1314,13 @@ static int ring_launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipSt
 }
 
 template <int KS>
+static int ring_launch_half(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    static std::atomic<unsigned long long> done{0};
+    return ring_launch_kernel(k_channelize_mfma_s16_ring_half<KS>, "k_channelize_mfma_s16_ring", RingGeo<KS, false>::THREADS, a, blocks, lds, stream, done);
+}
+
+template <int KS>
 static int ring_launch_short(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t stream)
 {
     static std::atomic<unsigned long long> done{0};
@@ -1307,6 +1367,11 @@ static int ring_launch_multi(const RingMultiArgs &m, unsigned blocks, size_t lds
         }
     }
     if (skipk) return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS, false, true>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[6]);
+    if constexpr (KS <= 8 && IQA_RING_HALF_STEP != 0 && IQA_RING_SPLIT_STAGE != 0) {
+        const int rem = (2 * m.c.D) & 31;  // values in the row's last k step
+        if (rem != 0 && rem <= 16)
+            return ring_launch_kernel(k_channelize_mfma_s16_ring_multi_half<KS>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[7]);
+    }
     return ring_launch_kernel(k_channelize_mfma_s16_ring_multi<KS>, "k_channelize_mfma_s16_ring_multi", RingGeo<KS, false>::THREADS, m, blocks, lds, stream, done[0]);
 }
 
@@ -1475,6 +1540,17 @@ int mfma_ring_launch(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t
             case 2: return ring_launch_one<13, 2, false>(a, blocks, lds, stream);    // per-wave barrier-wait / work cycles
             case 18: return ring_launch_one<13, 18, false>(a, blocks, lds, stream);  // the same without the DMA stream
             default: break;
+        }
+    }
+    if (IQA_RING_HALF_STEP != 0 && IQA_RING_SPLIT_STAGE != 0 && !dbg && !acc64 && a.range >= 512 && a.ksteps <= 8 && !a.high_taps_only) {
+        const int rem = (2 * a.D) & 31;  // values in the row's last k step
+        if (rem != 0 && rem <= 16) {
+            switch (a.ksteps) {
+#define RG_HALF(K) case K: return ring_launch_half<K>(a, blocks, lds, stream)
+                RG_HALF(1); RG_HALF(2); RG_HALF(3); RG_HALF(4); RG_HALF(5); RG_HALF(6); RG_HALF(7); RG_HALF(8);
+#undef RG_HALF
+                default: break;
+            }
         }
     }
     if (!dbg && !acc64 && a.range < 512) {  // short launch (int32 sums): same code, its own kernel name
