@@ -27,7 +27,7 @@
 // planes per slot; the multiplying waves read their MFMA operands as they lie in LDS (IQA_RING_SPLIT_STAGE below says what
 // that bought).  The ring of such a kernel is two slots per parity in LDS plus two or three rounds of loads in the loaders'
 // registers; the loaders also emit.  The text above describes the LDS-DMA form, which remains for uint8 captures and for
-// 14..16 k steps.
+// 14..16 k steps.  Up to 8 k steps a row whose last k step is at most half full ends in 32x32x16 MFMAs (the ..._half kernels).
 //
 // A contiguous slot is 1024*(2*KS + 1) bytes >= 32 rows at a pitch of D/4 (+1) 16-byte units (KS = ceil(2D/32) k steps;
 // the K padding of the last k step reads on into the next row, against zero taps); a tile takes 2*KS + 1 DMA
