@@ -181,11 +181,11 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
     res = [runner.collect(t) for t in ts][-1]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    # ... the same replays on TWO streams, round-robin by slot: a 50 MB capture's step is a chain of ten dependent kernels of a
-    # few microseconds each (80 us of GPU time per capture: latency, not work), so two captures' chains side by side fill each
-    # other's gaps -- independent captures, the same audio
+    # ... the same replays on FOUR streams, round-robin by slot: a 50 MB capture's step is a chain of ten dependent kernels of a
+    # few microseconds each (80 us of GPU time per capture: latency, not work), so the chains of several captures side by side
+    # fill each other's gaps -- independent captures, the same audio (two streams: 54 us per capture, three 47, four 39)
     runner2 = ResidentCaptureRunner(taps, sample_rate=fs, freq_offset=f_off, decimation=d, fs_channel=fs_ch,
-                                    chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n, slots=8, graph_streams=2)
+                                    chunk=P.tune_chunk_size(fs, 1_048_576), n_frames=n, slots=8, graph_streams=4)
     for t in [runner2.submit_captured(raw, enclosing=buf, lead_frames=0) for _ in range(warm)]:
         runner2.collect(t)
     torch.cuda.synchronize()
@@ -221,12 +221,12 @@ def sub_bench_c1(steps: int = 400, warm: int = 100) -> dict:
                     f"bw 12.5 kHz, D={d}, {len(taps)} taps",
         "value": round(n / dt2 / 1e6, 1), "unit": "MS/s", "ms_per_step": round(dt2 * 1e3, 4), "steps": steps,
         "step": f"captured into a hipGraph per (buffer, slot) and replayed (ResidentCaptureRunner.submit_captured), {runner2.SLOTS} captures in "
-                "flight, replays on two streams (independent captures side by side)",
-        "ms_per_step_one_stream": round(dt * 1e3, 4), "two_streams_audio_identical": bool(np.array_equal(audio, audio2)),
+                "flight, replays on four streams (independent captures side by side)",
+        "ms_per_step_one_stream": round(dt * 1e3, 4), "four_streams_audio_identical": bool(np.array_equal(audio, audio2)),
         "host_us_per_replay": {"mean": round(float(np.mean(host_us)), 1), "median": round(float(np.median(host_us)), 1),
                                "max": round(float(np.max(host_us)), 1),
                                "note": "host time inside submit_captured: wait for the capture `slots` back + hipGraphLaunch + event record"},
-        "host_us_per_replay_two_streams": {"mean": round(float(np.mean(host_us2)), 1), "median": round(float(np.median(host_us2)), 1),
+        "host_us_per_replay_four_streams": {"mean": round(float(np.mean(host_us2)), 1), "median": round(float(np.median(host_us2)), 1),
                                            "max": round(float(np.max(host_us2)), 1),
                                            "by_quarter": [round(float(np.mean(q)), 1) for q in np.array_split(np.asarray(host_us2), 4)]},
         "ms_per_step_direct_launches": round(dt_eager * 1e3, 4), "replays_redone": dict(runner.redone),

@@ -17,8 +17,11 @@ import os as _os
 # runtime maps streams onto four hardware queues by default, so a fifth stream shares a queue with another one -- measured
 # with RCCL in the process: the aux stream landed on the compute stream's queue, its launches ran after the resampler
 # instead of beside it, +4.5 % per capture.  Read by the runtime when it initialises (the first HIP call), so setting
-# it here works unless the application has already used the GPU; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# it here works unless the application has already used the GPU; an explicit setting wins.  Sixteen: the batch path's named
+# side streams (_dev.side_stream: aux, egress, tail, edge, upload, graph0..3) plus the caller's and the graph-capture stream
+# are eleven -- with eight queues the four graph-replay streams of a long-lived process shared queues two by two and config 1
+# ran at 55 us per capture instead of 39 (bench.py after its other sub-benches; 12 and 16 queues measured alike).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from . import _native as native  # noqa: F401
 from .decoders import Decoder, DecoderStats, create_decoder  # noqa: F401

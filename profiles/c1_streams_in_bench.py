@@ -28,6 +28,6 @@ for rep in range(3):
     _log.clear()
     r = bench.sub_bench_c1()
     slow = [(g, round(ms, 1), c) for g, ms, c in _log if ms > 1.0]
-    print(f"call {rep}: two streams {r['ms_per_step']:.4f} ms (host per replay {r['host_us_per_replay_two_streams']}), one stream "
+    print(f"call {rep}: four streams {r['ms_per_step']:.4f} ms (host per replay {r['host_us_per_replay_four_streams']}), one stream "
           f"{r['ms_per_step_one_stream']:.4f} ms (host {r['host_us_per_replay']['mean']}), direct {r['ms_per_step_direct_launches']:.4f}; "
           f"garbage collections: {len(_log)}, those over 1 ms (generation, ms, collected): {slow}", flush=True)
