@@ -649,7 +649,7 @@ def main() -> None:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (see iq_to_audio_amd/__init__.py; before the runtime initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # (see iq_to_audio_amd/__init__.py; before the runtime initialises)
     if args.axis == "channels":
         return main_channel_axis(args, json_fd)
     import torch
