@@ -769,7 +769,8 @@ def main() -> None:
         n_all = n_untimed + args.steps
         period = [ev_k0[i].elapsed_time(ev_k0[i + 1]) for i in range(n_all - 1)]
         kern = [ev_k0[i].elapsed_time(ev_k1[i]) for i in range(n_all)]
-        pick = sorted(set(list(range(0, min(n_all - 1, 40))) + list(range(40, n_all - 1, max(1, n_all // 60)))))
+        pick = (list(range(n_all - 1)) if n_all <= 200 else
+                sorted(set(list(range(0, min(n_all - 1, 40))) + list(range(40, n_all - 1, max(1, n_all // 60))))))
         print("step: period_ms kernel_ms", " | ".join(f"{i}: {period[i]:.3f} {kern[i]:.3f}" for i in pick), file=sys.stderr)
     kern_avg_ms = float(np.mean(kern_ms))
     ms_per_step = elapsed / args.steps * 1e3

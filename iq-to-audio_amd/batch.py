@@ -218,8 +218,9 @@ class ResidentCaptureRunner:
         with D.on_stream(self.egress, self.compute):
             t["pcm"].record_stream(self.egress)
             host = t["slot"]["pcm_host"]
+            # (ungated = the last capture of a batch, nothing to share the GPU with: as many workgroups as the link takes)
             N.call("iqa_trickle_copy", N.ptr(t["pcm"]), c_void_p(host.data_ptr()), c_int64(host.numel() * host.element_size()),
-                   c_int32(self.egress_workgroups), N.stream_ptr())
+                   c_int32(self.egress_workgroups if gate is not None else max(self.egress_workgroups, 64)), N.stream_ptr())
             t["done"].record(self.egress)
         t["egress_queued"] = True
         self._egress_pending = None
