@@ -57,6 +57,7 @@ class ResidentCaptureRunner:
     # that channelizer ends, and with two buffers the host could not queue capture i + 2 before: a bubble of one host
     # submission per capture (config 4's unit: 1.35 ms per capture for a 0.95 ms kernel).
     SLOTS = 3
+    probe_behind_channelizer = bool(int(__import__("os").environ.get("IQA_PROBE_BEHIND", "1")))  # submit(resident=True): see _chain
 
     def __init__(self, taps: np.ndarray, *, sample_rate: float, freq_offset: float, decimation: int, fs_channel: float,
                  chunk: int, n_frames: int, demod_mode: str = "nfm", deemph_us: float = 300.0, agc_enabled: bool = True,
@@ -130,8 +131,12 @@ class ResidentCaptureRunner:
         return pick_precision(self._kernel_for(sign), self.base_precision, self.demod_args["mode"], probe.power, probe.wideband_rms,
                               self.guard, memo)
 
-    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None, resident: bool = False, probe=None, precision: str | None = None):
-        """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later."""
+    def _chain(self, raw_dev, slot, sign: int, events=None, halo=None, resident: bool = False, probe=None, precision: str | None = None,
+               make_probe=None):
+        """Channelizer, demod, resample, PCM16 for one capture on the compute stream; the D2H is queued later.
+        ``make_probe`` (resident captures): called right BEHIND the channelizer's launch -- the probes go to the aux stream and
+        wait for nothing on the compute stream, so queueing them first only delays the launch an idle GPU is waiting for (the
+        first capture behind a synchronise: ~0.1 ms of host time)."""
         torch = D.torch_mod()
         chan = Channelizer(self.taps, sample_rate=self.fs, freq_offset=self.f_off, mix_sign=sign, decimation=self.d,
                            fmt=self.fmt, iq_order=self.iq_order, precision=precision or self.base_precision)
@@ -149,6 +154,8 @@ class ResidentCaptureRunner:
             gate.record(self.compute)
         prev = self._egress_pending
         chan.process(raw_dev, out_dev=slot["z"], events=events, last_block=True, halo=halo, edge_stream=side)
+        if make_probe is not None:
+            probe = make_probe()
         if events is None:
             ring_done = torch.cuda.Event()
             ring_done.record(self.compute)
@@ -186,7 +193,7 @@ class ResidentCaptureRunner:
         done = torch.cuda.Event()
         # tail_done: recorded lazily (tail_event) -- the next capture's gate lies behind it anyway
         ticket = dict(chan=chan, dem=dem, pcm=pcm, done=done, tail_done=tail_done, kernel=chan._kernel.last_kernel,
-                      slot=slot, egress_queued=False, resident=resident, precision=chan.precision)
+                      slot=slot, egress_queued=False, resident=resident, precision=chan.precision, probe=probe)
         self._egress_pending = ticket
         return ticket
 
@@ -255,11 +262,14 @@ class ResidentCaptureRunner:
             # short kernels, not with a channelizer (small kernels beside it starve and stretch it); the earlier user
             # of this slot's buffers finished before that
             self.aux.wait_event(self._ring_done)
-        probe = self._probe(raw_dev, resident)
         sign = self.override if self.override is not None else self._spec_sign
         halo = (enclosing, int(lead_frames)) if enclosing is not None else None
-        ticket = self._chain(raw_dev, slot, sign, events, halo, resident, probe, self._spec_precision)
-        ticket.update(probe=probe, sign=sign, raw=raw_dev, halo=halo)
+        if resident and self.probe_behind_channelizer:
+            ticket = self._chain(raw_dev, slot, sign, events, halo, resident, None, self._spec_precision,
+                                 make_probe=lambda: self._probe(raw_dev, True))
+        else:
+            ticket = self._chain(raw_dev, slot, sign, events, halo, resident, self._probe(raw_dev, resident), self._spec_precision)
+        ticket.update(sign=sign, raw=raw_dev, halo=halo)
         slot["busy"] = ticket
         return ticket
 
